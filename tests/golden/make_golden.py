@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules on CPU fp32.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).
+Nothing of the reference is copied: the script imports it in place, feeds it the
+deterministic inputs/weights of oracle/detgen.py + oracle.devit_oracle.make_state
+and stores OUTPUTS only.
+
+Harness-side shims (no edit of /root/reference):
+  1. builtins.partial / builtins.nn  -- models/utils/config.py:4 uses them unimported.
+  2. stand-in `timm` modules -- timm==0.5.4 (README.md:18) is not installed and not
+     vendored.  Only PatchEmbed (Conv2d 16/16 + flatten/transpose), DropPath (delegates
+     to the reference's in-tree models/utils/stochastic_depth.py:8-25) and
+     SoftTargetCrossEntropy carry arithmetic.
+  3. torch.Tensor.get_device -> self.device for CPU tensors (models/de_vit.py:42,78).
+
+Usage:  python tests/golden/make_golden.py            (writes next to this file)
+"""
+import builtins
+import functools
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle.detgen import det_array, det_labels  # noqa: E402
+from oracle import devit_oracle as O  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shims
+def install_shims():
+    builtins.partial = functools.partial
+    builtins.nn = nn
+
+    spec = importlib.util.spec_from_file_location("_ref_sd", f"{REF}/models/utils/stochastic_depth.py")
+    sd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sd)
+
+    class PatchEmbed(nn.Module):
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True):
+            super().__init__()
+            self.img_size = (img_size, img_size)
+            self.patch_size = (patch_size, patch_size)
+            self.grid_size = (img_size // patch_size, img_size // patch_size)
+            self.num_patches = self.grid_size[0] * self.grid_size[1]
+            self.flatten = flatten
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+            self.norm = nn.Identity()
+
+        def forward(self, x):
+            x = self.proj(x)
+            x = x.flatten(2).transpose(1, 2)
+            return self.norm(x)
+
+    class SoftTargetCrossEntropy(nn.Module):
+        def forward(self, x, target):
+            return torch.sum(-target * torch.nn.functional.log_softmax(x, dim=-1), dim=-1).mean()
+
+    registry = {}
+
+    def register_model(fn):
+        registry[fn.__name__] = fn
+        return fn
+
+    def create_model(name, pretrained=False, **kw):
+        kw = {k: v for k, v in kw.items() if v is not None}
+        return registry[name](pretrained=pretrained, **kw)
+
+    def trunc_normal_(t, mean=0., std=1., a=-2., b=2.):
+        return nn.init.trunc_normal_(t, mean, std, a, b)
+
+    def named_apply(fn, module, name="", depth_first=True, include_root=False):
+        for cn, cm in module.named_children():
+            named_apply(fn, cm, ".".join((name, cn)) if name else cn, depth_first, True)
+        if include_root:
+            fn(module=module, name=name)
+        return module
+
+    def mk(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mk("timm")
+    mk("timm.models", create_model=create_model)
+    mk("timm.models.registry", register_model=register_model)
+    mk("timm.models.vision_transformer", _cfg=lambda **kw: dict(kw))
+    mk("timm.models.layers", PatchEmbed=PatchEmbed, DropPath=sd.DropPath, trunc_normal_=trunc_normal_,
+       lecun_normal_=trunc_normal_, Mlp=None)
+    mk("timm.models.helpers", named_apply=named_apply, adapt_input_conv=None)
+    mk("timm.loss", SoftTargetCrossEntropy=SoftTargetCrossEntropy)
+
+    orig = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: self.device if self.device.type == "cpu" else orig(self)
+    sys.path.insert(0, REF)
+    return registry, create_model, sd
+
+
+class RandQueue:
+    """Replaces torch.rand inside DropPath so the masks are data we control."""
+
+    def __init__(self, name, keep_probs):
+        self.name, self.n, self.scales, self.keep = name, 0, [], keep_probs
+
+    def __call__(self, shape, dtype=None, device=None):
+        u = det_array(f"{self.name}/{self.n}", tuple(shape), std=1.0)
+        u = torch.from_numpy(np.abs(u) % 1.0).to(dtype or torch.float32)
+        kp = self.keep[self.n]
+        self.scales.append(torch.floor(kp + u).reshape(-1) / kp)
+        self.n += 1
+        return u
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def load_into(model, st):
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(st.keys()), "state_dict key order differs from oracle.state_keys"
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(st[k].shape), k
+    model.load_state_dict(st)
+
+
+def main():
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    _, create_model, _ = install_shims()
+    import models.de_vit as de_vit          # noqa: E402  (reference)
+    import utils.losses as ref_losses       # noqa: E402  (reference)
+
+    C = 25
+    gs, gt = O.GEOMETRY["dedeit"], O.GEOMETRY["deit_base_distilled_patch16_224"]
+    st_s, st_t = O.make_state(gs, C, "S"), O.make_state(gt, C, "T")
+
+    student = create_model("dedeit", pretrained=False, num_classes=C, drop_rate=0.0, drop_path_rate=0.0,
+                           drop_block_rate=None)
+    # teacher = the dict-API class with DeiT-B hyper-parameters
+    teacher = de_vit.VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4,
+                                       qkv_bias=True, norm_layer=functools.partial(nn.LayerNorm, eps=1e-6),
+                                       distilled=True, num_classes=C)
+    load_into(student, st_s)
+    load_into(teacher, st_t)
+
+    # ---- statedict / API contract ------------------------------------------------
+    contract = {
+        "dedeit_keys": [[k, list(v.shape)] for k, v in student.state_dict().items()],
+        "deitb_keys": [[k, list(v.shape)] for k, v in teacher.state_dict().items()],
+        "n_mlp": sum(1 for m in student.modules() if "Mlp" in str(m) and "Attention" not in str(m)),
+        "n_attn": sum(1 for m in student.modules() if "Attention" in str(m) and "Mlp" not in str(m)),
+        "n_params_dedeit_c25": sum(p.numel() for p in student.parameters()),
+        "n_params_deitb_c25": sum(p.numel() for p in teacher.parameters()),
+        "no_weight_decay": sorted(student.no_weight_decay()),
+    }
+    with open(os.path.join(HERE, "statedict_keys.json"), "w") as f:
+        json.dump(contract, f, indent=0)
+
+    img = torch.from_numpy(det_array("img8", (8, 3, 224, 224)))
+
+    # ---- module fixtures (block 5 of each model, x ~ LayerNorm-scale input) -----------
+    for tag, model, D, H in (("S", student, 384, 6), ("T", teacher, 768, 12)):
+        x = torch.from_numpy(det_array(f"x/{tag}", (2, 198, D), std=1.0)).requires_grad_(True)
+        blk = model.blocks[5]
+        blk.eval()
+        ng = torch.from_numpy((np.abs(det_array(f"ng/{tag}", (4 * D,))) > 0.4).astype(np.float32))
+        hg = torch.ones(H)
+        hg[1] = 0.0
+        # Mlp, gate ones / masked
+        y1 = blk.mlp(x)
+        gx, gw = torch.autograd.grad(y1.square().sum(), [x, blk.mlp.fc1.weight])
+        blk.mlp.gate = ng
+        y2 = blk.mlp(x)
+        nout = blk.mlp.neuron_output.detach().clone()
+        blk.mlp.gate = torch.ones(4 * D)
+        # Attention, gate ones / head 1 zeroed
+        a1 = blk.attn(x, True)
+        ga, = torch.autograd.grad(a1["output"].square().sum(), [x])
+        blk.attn.gate = hg
+        a2 = blk.attn(x, True)
+        hout = blk.attn.head_output.detach().clone()
+        blk.attn.gate = torch.ones(H)
+        b1 = blk(x, output_qkv=True, output_att=True)
+        sub = lambda t: t[:, ::9]   # 22 of the 198 tokens: keeps each fixture < 1 MB
+        save(f"module_{tag}", mlp_y=sub(y1), mlp_dx=sub(gx), mlp_dw1_rows=gw[:8], mlp_y_gated=sub(y2),
+             mlp_neuron_output_sum=nout.sum(dim=(0, 1)), neuron_gate=ng,
+             attn_y=sub(a1["output"]), attn_q=a1["qkv"][0][:, :, :16], attn_k=a1["qkv"][1][:, :, :16],
+             attn_v=a1["qkv"][2][:, :, :16], attn_dx=sub(ga), attn_y_gated=sub(a2["output"]),
+             attn_head_output_sum=hout.sum(dim=(0, 1)), head_gate=hg,
+             block_y=sub(b1["output"]), block_att=sub(b1["attention"]))
+
+    # ---- whole-model fixtures ------------------------------------------------------
+    for tag, model in (("dedeit", student), ("deitb", teacher)):
+        model.eval()
+        with torch.no_grad():
+            logits = model(img)
+            d = model(img, distill_token=True, output_qkv=True, output_att=True, output_emb=True,
+                      output_encoders=True)
+        assert torch.equal(d["output"], logits)
+        q, k, v = d["qkv"][5]
+        model.train()
+        with torch.no_grad():
+            tr = model(img)
+        enc_stats = np.stack([[e.mean().item(), e.abs().mean().item()] for e in d["encoder"]])
+        save(f"model_{tag}", logits=logits, top1=logits.argmax(1), train_cls=tr[0], train_dist=tr[1],
+             q5=q[:2, :, :24], k5=k[:2, :, :24], v5=v[:2, :, :24], att5=d["attention"][5][:2, :24],
+             enc_last=d["encoder"][-1][:2, :24], enc_stats=enc_stats,
+             last_cls=d["last_tokens"][0], last_dist=d["last_tokens"][1])
+        # bf16 autocast run of the same reference module: defines the bf16-mode tolerance
+        model.eval()
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            lb = model(img)
+        save(f"model_{tag}_bf16", logits=lb.float())
+
+    # ---- loss fixtures -------------------------------------------------------------
+    lo = torch.from_numpy(det_array("lo", (8, C), std=1.5)).requires_grad_(True)
+    lk = torch.from_numpy(det_array("lk", (8, C), std=1.5)).requires_grad_(True)
+    lt = torch.from_numpy(det_array("lt", (8, C), std=2.0))
+    y1, y2 = det_labels("y1", 8, C), det_labels("y2", 8, C)
+    eps, lam = 0.1, 0.7
+    oh = lambda y: torch.full((8, C), eps / C).scatter_(1, torch.from_numpy(y)[:, None], 1 - eps + eps / C)
+    soft = oh(y1) * lam + oh(y2) * (1 - lam)
+    base = sys.modules["timm.loss"].SoftTargetCrossEntropy()
+    res = {}
+    for kind in ("hard", "soft"):
+        crit = ref_losses.DistillLoss(base, kind, 0.5, 1.0 if kind == "hard" else 3.0)
+        l = crit((lo, lk), lt, soft)
+        g = torch.autograd.grad(l, [lo, lk])
+        res.update({f"{kind}_loss": l, f"{kind}_dlo": g[0], f"{kind}_dlk": g[1]})
+    save("loss_cls", soft_targets=soft, **res)
+
+    tf = torch.from_numpy(det_array("tf", (2, 198, 3, 12, 64), std=0.25)).permute(2, 0, 3, 1, 4)[1]
+    sf = torch.from_numpy(det_array("sf", (2, 198, 3, 6, 64), std=0.25)).permute(2, 0, 3, 1, 4)[1]
+    sf = sf.detach().requires_grad_(True)
+    l = ref_losses.feature_relation_loss(tf, sf)
+    g, = torch.autograd.grad(l, [sf])
+    save("loss_relation", loss=l, dstudent=g[:, :, ::9])
+
+    # ---- one distillation step (engine.py:68-106) with recorded DropPath masks --------
+    student_dp = create_model("dedeit", pretrained=False, num_classes=C, drop_rate=0.0, drop_path_rate=0.1,
+                              drop_block_rate=None)
+    load_into(student_dp, st_s)
+    student_dp.train()
+    teacher.eval()
+    dpr = [x.item() for x in torch.linspace(0, 0.1, 12)]
+    keep = []
+    for i in range(1, 12):
+        keep += [1 - dpr[i], 1 - dpr[i]]
+    rq = RandQueue("dp", keep)
+    y1, y2 = det_labels("sy1", 8, C), det_labels("sy2", 8, C)
+    soft8 = oh(y1) * lam + oh(y2) * (1 - lam)
+    crit = ref_losses.DistillLoss(base, "hard", 0.5, 1.0)
+    real_rand = torch.rand
+    torch.rand = rq
+    try:
+        outputs = student_dp(img, output_qkv=True)
+    finally:
+        torch.rand = real_rand
+    with torch.no_grad():
+        t_out = teacher(img, output_qkv=True)
+    cls_loss = crit(outputs=outputs["output"], teacher_outputs=t_out["output"], labels=soft8)
+    sq, tq = outputs["qkv"][12 // 2 - 1], t_out["qkv"][12 // 2 - 1]
+    ql, kl, vl = [ref_losses.feature_relation_loss(tv, sv) / 12 for sv, tv in zip(sq, tq)]
+    gama = (0.2, 0.1, 0.3)
+    loss = cls_loss + gama[0] * ql + gama[1] * kl + gama[2] * vl
+    loss.backward()
+    names = [n for n, _ in student_dp.named_parameters()]
+    gn = np.array([p.grad.norm().item() for _, p in student_dp.named_parameters()])
+    grads = dict(student_dp.named_parameters())
+    dp_scales = torch.stack([torch.ones(8), torch.ones(8)] + rq.scales).reshape(12, 2, 8)
+    save("step_bs8", loss=loss, cls_loss=cls_loss, q_loss=ql, k_loss=kl, v_loss=vl, soft_targets=soft8,
+         dp_scales=dp_scales, grad_norms=gn, teacher_logits=t_out["output"],
+         stu_cls=outputs["output"][0], stu_dist=outputs["output"][1],
+         g_head_w=grads["head.weight"].grad, g_head_dist_w=grads["head_dist.weight"].grad,
+         g_qkv5_w_rows=grads["blocks.5.attn.qkv.weight"].grad[::48],
+         g_fc1_0_rows=grads["blocks.0.mlp.fc1.weight"].grad[::64],
+         g_fc2_11_rows=grads["blocks.11.mlp.fc2.weight"].grad[::16],
+         g_pos=grads["pos_embed"].grad[0, ::8], g_cls=grads["cls_token"].grad,
+         g_patch_w=grads["patch_embed.proj.weight"].grad[::16].reshape(-1, 768),
+         g_norm_w=grads["norm.weight"].grad, g_ln1_5_b=grads["blocks.5.norm1.bias"].grad)
+    with open(os.path.join(HERE, "step_param_names.json"), "w") as f:
+        json.dump(names, f)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
