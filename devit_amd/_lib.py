@@ -1,0 +1,110 @@
+"""ctypes binding of libdevit_hip.so (C ABI declared in include/devit_hip.h).
+
+The product path has NO fallback: if the shared library is missing, or the current device is
+not an MI355X (gfx950), every op raises.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdevit_hip.so")
+
+# devit_epilogue_kind
+EPI_STORE_BF16, EPI_GELU_BF16, EPI_RESIDUAL_F32, EPI_PATCH_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_STORE_F32 = range(7)
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("kind", C.c_int), ("out", C.c_void_p), ("ldc", C.c_int), ("bias", C.c_void_p),
+                ("colscale", C.c_void_p), ("aux", C.c_void_p), ("aux_in", C.c_void_p), ("res", C.c_void_p),
+                ("rowscale", C.c_void_p), ("rows_per_scale", C.c_int), ("pos", C.c_void_p),
+                ("patch_tokens", C.c_int), ("extra_tokens", C.c_int), ("exact_gelu", C.c_int),
+                ("out_batch_stride", C.c_longlong), ("m_valid", C.c_int)]
+
+
+class Operand(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int), ("kmajor", C.c_int), ("row_group", C.c_int),
+                ("row_skip", C.c_int), ("batch_stride", C.c_longlong)]
+
+
+class DevitError(RuntimeError):
+    pass
+
+
+_P, _I, _F, _Z, _LL = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
+
+# name -> (restype, argtypes); must list every symbol of include/devit_hip.h (tests check this)
+SIGNATURES = {
+    "devit_version": (_I, []),
+    "devit_last_error": (C.c_char_p, []),
+    "devit_check_device": (_I, [_I]),
+    "devit_gemm_bf16": (_I, [C.POINTER(Operand), C.POINTER(Operand), _I, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
+    "devit_layernorm_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "devit_layernorm_bwd_workspace": (_Z, [_I, _I]),
+    "devit_layernorm_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _Z, _P]),
+    "devit_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "devit_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "devit_im2row_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "devit_embed_tokens": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "devit_embed_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "devit_cast_bf16": (_I, [_P, _P, _Z, _P]),
+    "devit_scale_cast_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "devit_colsum_workspace": (_Z, [_I, _I]),
+    "devit_colsum_bf16": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "devit_sgemm_small": (_I, [_P, _LL, _LL, _P, _LL, _LL, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "devit_sumsq_workspace": (_Z, []),
+    "devit_sumsq_f32": (_I, [_P, _Z, _P, _P, _Z, _P]),
+    "devit_adamw_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "devit_cls_distill_loss": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "devit_relation_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "devit_relation_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+_checked_devices = set()
+
+
+def load():
+    """Load libdevit_hip.so (no GPU needed to load; kernels need gfx950)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DevitError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or devit_amd/csrc/build.sh).  devit_amd has no CPU / PyTorch fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.devit_version() != 1:
+            raise DevitError("libdevit_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def require_device(t: torch.Tensor):
+    """Fail loudly unless `t` lives on a gfx950 GPU."""
+    if not t.is_cuda:
+        raise DevitError("devit_amd ops run on MI355X (gfx950) only; got a %s tensor. There is no CPU fallback "
+                         "(the CPU restatement lives in oracle/ and is test infrastructure)." % t.device)
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if idx not in _checked_devices:
+        call("devit_check_device", idx)
+        _checked_devices.add(idx)
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise DevitError(f"{name} failed ({rc}): {lib.devit_last_error().decode()}")
+    return rc
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,229 @@
+// LayerNorm forward / backward for the fp32 residual stream (one wave per token row).
+// HBM-bound: every row is read once (fwd) or read once + written once (bwd); statistics are fp32.
+// Replaces nn.LayerNorm(D, eps=1e-6) at models/de_vit.py:113,115,286 and its autograd backward.
+#include <type_traits>
+
+#include "devit_common.h"
+
+namespace {
+
+constexpr int LN_MAX_NV = 8;  // D <= 1024, D % 128 == 0 ; lane holds NV float2 pairs
+
+struct LnFwdArgs {
+  const float* x;
+  const float* gamma;
+  const float* beta;
+  __bf16* y_bf16;
+  float* y_f32;
+  float* mean;
+  float* rstd;
+  int rows, D, in_group, in_stride;
+  float eps;
+};
+
+__device__ __forceinline__ size_t ln_in_row(int r, int group, int stride) {
+  return group > 0 ? (size_t)(r / group) * stride + (r % group) : (size_t)r;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  f32x2 gm[NV], bt[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *(const f32x2*)(a.gamma + v * 128 + lane * 2);
+    bt[v] = *(const f32x2*)(a.beta + v * 128 + lane * 2);
+  }
+  const float invD = 1.0f / (float)a.D;
+  for (int r = wave_global; r < a.rows; r += nwaves) {
+    const float* xr = a.x + ln_in_row(r, a.in_group, a.in_stride) * a.D;
+    f32x2 xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xv[v] = *(const f32x2*)(xr + v * 128 + lane * 2);
+      s += xv[v][0] + xv[v][1];
+    }
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float d0 = xv[v][0] - mu, d1 = xv[v][1] - mu;
+      q += d0 * d0 + d1 * d1;
+    }
+    const float rs = rsqrtf(wave_sum(q) * invD + a.eps);
+    if (lane == 0) {
+      if (a.mean) a.mean[r] = mu;
+      if (a.rstd) a.rstd[r] = rs;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float y0 = (xv[v][0] - mu) * rs * gm[v][0] + bt[v][0];
+      const float y1 = (xv[v][1] - mu) * rs * gm[v][1] + bt[v][1];
+      const size_t o = (size_t)r * a.D + v * 128 + lane * 2;
+      if (a.y_bf16) {
+        bf16x2 ob = {f2bf(y0), f2bf(y1)};
+        *(bf16x2*)(a.y_bf16 + o) = ob;
+      }
+      if (a.y_f32) {
+        f32x2 of = {y0, y1};
+        *(f32x2*)(a.y_f32 + o) = of;
+      }
+    }
+  }
+}
+
+struct LnBwdArgs {
+  const void* dy;       // [rows][D] bf16 or f32 (dense, row r)
+  const float* x;       // forward input, physical row map as in fwd
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* dres;    // [phys rows][D] f32 upstream residual-stream gradient or NULL
+  float* dx;            // [phys rows][D] f32 = dres + LN'(dy)
+  __bf16* dx_bf16;      // optional bf16 copy of rowscale * dx (branch gradient for the next GEMMs)
+  const float* rowscale;
+  int rows_per_scale;
+  float* partial;       // [grid][2][D] column partial sums (dgamma, dbeta)
+  int rows, D, in_group, in_stride, dy_is_f32;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+  __shared__ float red[4][2][LN_MAX_NV * 128];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave_global = blockIdx.x * 4 + wv;
+  const int nwaves = gridDim.x * 4;
+  f32x2 gm[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *(const f32x2*)(a.gamma + v * 128 + lane * 2);
+    dg[v] = (f32x2){0.f, 0.f};
+    db[v] = (f32x2){0.f, 0.f};
+  }
+  const float invD = 1.0f / (float)a.D;
+  for (int r = wave_global; r < a.rows; r += nwaves) {
+    const size_t pr = ln_in_row(r, a.in_group, a.in_stride);
+    const float* xr = a.x + pr * a.D;
+    const float mu = a.mean[r], rs = a.rstd[r];
+    f32x2 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = v * 128 + lane * 2;
+      const f32x2 xv = *(const f32x2*)(xr + c);
+      f32x2 dyv;
+      if (a.dy_is_f32) {
+        dyv = *(const f32x2*)((const float*)a.dy + (size_t)r * a.D + c);
+      } else {
+        const bf16x2 t = *(const bf16x2*)((const __bf16*)a.dy + (size_t)r * a.D + c);
+        dyv = (f32x2){bf2f(t[0]), bf2f(t[1])};
+      }
+      xh[v] = (f32x2){(xv[0] - mu) * rs, (xv[1] - mu) * rs};
+      g[v] = dyv * gm[v];
+      dg[v] += dyv * xh[v];
+      db[v] += dyv;
+      s1 += g[v][0] + g[v][1];
+      s2 += g[v][0] * xh[v][0] + g[v][1] * xh[v][1];
+    }
+    const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+    const float rsc = (a.dx_bf16 && a.rowscale) ? a.rowscale[pr / a.rows_per_scale] : 1.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const size_t o = pr * a.D + v * 128 + lane * 2;
+      f32x2 d = (f32x2){rs * (g[v][0] - m1 - xh[v][0] * m2), rs * (g[v][1] - m1 - xh[v][1] * m2)};
+      if (a.dres) d += *(const f32x2*)(a.dres + o);
+      *(f32x2*)(a.dx + o) = d;
+      if (a.dx_bf16) {
+        bf16x2 ob = {f2bf(d[0] * rsc), f2bf(d[1] * rsc)};
+        *(bf16x2*)(a.dx_bf16 + o) = ob;
+      }
+    }
+  }
+  // block reduction of the column sums -> partial[block][{dgamma,dbeta}][D]
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    *(f32x2*)&red[wv][0][v * 128 + lane * 2] = dg[v];
+    *(f32x2*)&red[wv][1][v * 128 + lane * 2] = db[v];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * a.D; i += 256) {
+    const int which = i / a.D, c = i - which * a.D;
+    a.partial[((size_t)blockIdx.x * 2 + which) * a.D + c] =
+        red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+// out[c] (+)= sum_p partial[p][c]   (deterministic order)
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* partial, int nparts, int ncols,
+                                                              float* out0, float* out1, int D, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * ncols + c];
+  float* dst = c < D ? out0 + c : out1 + (c - D);
+  *dst = accumulate ? *dst + s : s;
+}
+
+template <typename Args, typename F>
+int dispatch_nv(int D, F&& f) {
+  switch (D / 128) {
+    case 1: f(std::integral_constant<int, 1>()); return 0;
+    case 2: f(std::integral_constant<int, 2>()); return 0;
+    case 3: f(std::integral_constant<int, 3>()); return 0;
+    case 4: f(std::integral_constant<int, 4>()); return 0;
+    case 6: f(std::integral_constant<int, 6>()); return 0;
+    case 8: f(std::integral_constant<int, 8>()); return 0;
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+extern "C" int devit_layernorm_fwd(const float* x, int rows, int D, int in_group, int in_stride,
+                                   const float* gamma, const float* beta, float eps, void* y_bf16, float* y_f32,
+                                   float* mean, float* rstd, void* stream) {
+  DEVIT_CHECK(x && gamma && beta && (y_bf16 || y_f32), DEVIT_ERR_ARG, "devit_layernorm_fwd: null pointer");
+  DEVIT_CHECK(rows > 0 && D % 128 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE,
+              "devit_layernorm_fwd: D=%d must be a multiple of 128, <= 1024", D);
+  LnFwdArgs a{x, gamma, beta, (__bf16*)y_bf16, y_f32, mean, rstd, rows, D, in_group, in_stride, eps};
+  const int grid = rows < 4 * 2048 ? (rows + 3) / 4 : 2048;
+  int rc = dispatch_nv<LnFwdArgs>(D, [&](auto nv) {
+    hipLaunchKernelGGL((ln_fwd_kernel<decltype(nv)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  });
+  DEVIT_CHECK(rc == 0, DEVIT_ERR_SHAPE, "devit_layernorm_fwd: unsupported D=%d", D);
+  DEVIT_LAUNCH_CHECK();
+  return DEVIT_OK;
+}
+
+extern "C" size_t devit_layernorm_bwd_workspace(int rows, int D) {
+  const int grid = rows < 4 * 512 ? (rows + 3) / 4 : 512;
+  return (size_t)grid * 2 * D * sizeof(float);
+}
+
+extern "C" int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows, int D, int in_group,
+                                   int in_stride, const float* mean, const float* rstd, const float* gamma,
+                                   const float* dres, float* dx, void* dx_bf16, const float* rowscale,
+                                   int rows_per_scale, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  DEVIT_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, DEVIT_ERR_ARG,
+              "devit_layernorm_bwd: null pointer");
+  DEVIT_CHECK(rows > 0 && D % 128 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: D=%d", D);
+  DEVIT_CHECK(workspace_bytes >= devit_layernorm_bwd_workspace(rows, D), DEVIT_ERR_ARG,
+              "devit_layernorm_bwd: workspace too small");
+  DEVIT_CHECK(!rowscale || rows_per_scale > 0, DEVIT_ERR_ARG, "devit_layernorm_bwd: rows_per_scale");
+  const int grid = rows < 4 * 512 ? (rows + 3) / 4 : 512;
+  LnBwdArgs a{dy, x, mean, rstd, gamma, dres, dx, (__bf16*)dx_bf16, rowscale, rows_per_scale,
+              (float*)workspace, rows, D, in_group, in_stride, dy_is_f32};
+  int rc = dispatch_nv<LnBwdArgs>(D, [&](auto nv) {
+    hipLaunchKernelGGL((ln_bwd_kernel<decltype(nv)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  });
+  DEVIT_CHECK(rc == 0, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: unsupported D=%d", D);
+  DEVIT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, grid, 2 * D, dgamma, dbeta, D, accumulate);
+  DEVIT_LAUNCH_CHECK();
+  return DEVIT_OK;
+}

@@ -1,0 +1,423 @@
+"""MI355X-native mirror of the reference's gated ViT/DeiT module surface (models/de_vit.py).
+
+Same class names (`Mlp`, `Attention`, `Block`, `VisionTransformer`), constructor arguments, state_dict
+keys/order/shapes (155 tensors for distilled models), forward() return-type matrix
+(models/de_vit.py:316-334) and shrink contract (`gate`, `neuron_output`, `head_output`,
+`hidden_features`, `num_heads`; core/imp_rank.py).  The arithmetic runs in libdevit_hip.so only: modules
+own fp32 master parameters, keep bf16 copies for the MFMA GEMMs, and call devit_amd.ops.  A CPU tensor
+raises (no fallback); the CPU restatement used for parity lives in oracle/.
+
+The nn.Linear / nn.LayerNorm / nn.Conv2d children are parameter containers (so initialisation and
+checkpoint keys equal the reference's); their own forward() is never called.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .registry import register_model
+
+__all__ = ["Mlp", "Attention", "Block", "PatchEmbed", "VisionTransformer", "model_config", "dedeit", "devit"]
+
+
+def _w16(lin):
+    """bf16 GEMM copy of an nn.Linear / Conv2d weight, refreshed when the fp32 master changed.
+    (Flat optimizers that rewrite master + bf16 through the C ABI keep both in sync themselves.)"""
+    w = lin.weight
+    c = getattr(lin, "_w16", None)
+    if c is None or c[0] != w._version or c[1].device != w.device or c[2] != w.data_ptr():
+        buf = c[1] if (c is not None and c[1].device == w.device and c[1].numel() == w.numel()) else None
+        t = ops.cast_bf16(w.detach().reshape(w.shape[0], -1), buf)
+        lin._w16 = (w._version, t, w.data_ptr())
+        return t
+    return c[1]
+
+
+class _Gated:
+    """`gate` is a plain CPU float tensor attribute in the reference (de_vit.py:33,63), re-uploaded on every
+    forward (:42,:78).  Here the device copy is cached and all-ones gates are skipped."""
+
+    def _init_gate(self, n):
+        self._gate = torch.ones(n)
+        self._gate_dev = None
+
+    @property
+    def gate(self):
+        return self._gate
+
+    @gate.setter
+    def gate(self, value):
+        self._gate = value
+        self._gate_dev = None
+
+    def gate_on(self, device):
+        g = self._gate
+        if bool((g == 1).all()):
+            return None
+        if self._gate_dev is None or self._gate_dev.device != device:
+            self._gate_dev = g.detach().float().to(device).contiguous()
+        return self._gate_dev
+
+
+class Mlp(nn.Module, _Gated):
+    """fc1 -> exact GELU -> neuron gate -> fc2 (models/de_vit.py:21-47)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.hidden_features = hidden_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        if drop != 0.:
+            raise NotImplementedError("dropout p > 0 is not on the DeViT hot path (distill_sub.py --drop 0.0)")
+        self._init_gate(hidden_features)
+
+    def forward(self, x):
+        return _standalone_mlp(self, x)
+
+
+class Attention(nn.Module, _Gated):
+    """qkv -> softmax(q k^T / sqrt(hd)) v -> head gate -> proj (models/de_vit.py:50-87)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        if attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError("dropout p > 0 is not on the DeViT hot path")
+        if head_dim != 64:
+            raise NotImplementedError("the fused attention kernel is built for head_dim == 64 (all DeiT/ViT-16 models)")
+        self._init_gate(num_heads)
+
+    def forward(self, x, output_qkv=False):
+        return _standalone_attention(self, x, output_qkv)
+
+
+def qkv_views(qkv_packed, B, N, H):
+    """(q, k, v) strided views [B, H, N, hd] of the packed qkv GEMM output (de_vit.py:67-68)."""
+    hd = qkv_packed.shape[1] // (3 * H)
+    v = qkv_packed[: B * N].view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    q, k, vv = v[0], v[1], v[2]
+    for t in (q, k, vv):
+        t._devit_packed = (qkv_packed, B, N, H)   # lets losses.relation_losses_packed skip the re-pack
+    return q, k, vv
+
+
+class Block(nn.Module):
+    """models/de_vit.py:90-121.  Runs as one fused autograd node (ops.EncoderFn)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    @property
+    def drop_prob(self):
+        return self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.
+
+    def block_params(self, device):
+        bp = ops.BlockParams()
+        bp.n1w, bp.n1b = self.norm1.weight, self.norm1.bias
+        bp.qkv_w, bp.qkv_b = self.attn.qkv.weight, self.attn.qkv.bias
+        bp.proj_w, bp.proj_b = self.attn.proj.weight, self.attn.proj.bias
+        bp.n2w, bp.n2b = self.norm2.weight, self.norm2.bias
+        bp.fc1_w, bp.fc1_b = self.mlp.fc1.weight, self.mlp.fc1.bias
+        bp.fc2_w, bp.fc2_b = self.mlp.fc2.weight, self.mlp.fc2.bias
+        bp.qkv_w16, bp.proj_w16 = _w16(self.attn.qkv), _w16(self.attn.proj)
+        bp.fc1_w16, bp.fc2_w16 = _w16(self.mlp.fc1), _w16(self.mlp.fc2)
+        bp.num_heads = self.attn.num_heads
+        bp.head_gate, bp.neuron_gate = self.attn.gate_on(device), self.mlp.gate_on(device)
+        bp.dp_prob = self.drop_prob if self.training else 0.
+        bp.module = self
+        if bp.qkv_b is None:
+            raise NotImplementedError("qkv_bias=False is not used by any registered DeViT model")
+        return bp
+
+    def forward(self, x, output_qkv=False, output_att=False):
+        x_out, qkvs, atts, _ = run_blocks([self], x, self.training, output_qkv, output_att, False)
+        outputs = {'output': x_out}
+        outputs['qkv'] = qkvs[0] if output_qkv else None
+        outputs['attention'] = atts[0] if output_att else None
+        return outputs
+
+
+class DropPath(nn.Module):
+    """timm DropPath semantics (= models/utils/stochastic_depth.py:8-25): per-sample floor(keep + U)/keep."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        raise RuntimeError("DropPath is folded into the residual GEMM epilogue; it is never called directly")
+
+
+def draw_dp_scales(blocks_params, B, device, training):
+    scales, any_dp = [], False
+    for bp in blocks_params:
+        p = bp.dp_prob if training else 0.
+        if p > 0.:
+            keep = 1.0 - p
+            u = torch.rand((2, B), dtype=torch.float32, device=device)
+            sc = torch.floor(keep + u) / keep
+            scales.append((sc[0].contiguous(), sc[1].contiguous()))
+            any_dp = True
+        else:
+            scales.append(None)
+    return scales if any_dp else None
+
+
+def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=None, dp_scales="draw", exact_gelu=0):
+    """Run a list of Blocks as one EncoderFn node.  Returns (x, qkv tuples, att tensors, enc tensors)."""
+    L.require_device(x)
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, N, D = x.shape
+    bps = [b.block_params(x.device) for b in blocks]
+    if dp_scales == "draw":
+        dp_scales = draw_dp_scales(bps, B, x.device, training)
+    cfg = ops.EncoderCfg(bps, training, dp_scales, want_qkv, want_att, want_enc, exact_gelu=exact_gelu,
+                         grad_ready=grad_ready)
+    cfg.grad_enabled = torch.is_grad_enabled()
+    flat = [p for bp in bps for p in bp.all_params()]
+    outs = ops.EncoderFn.apply(x, cfg, *flat)
+    nb = len(blocks)
+    i = 1
+    qkvs = atts = encs = None
+    if want_qkv:
+        qkvs = [qkv_views(t, B, N, bps[j].num_heads) for j, t in enumerate(outs[i:i + nb])]
+        i += nb
+    if want_att:
+        atts = [t.view(B, N, D) for t in outs[i:i + nb]]
+        i += nb
+    if want_enc:
+        encs = list(outs[i:i + nb])
+    return outs[0], qkvs, atts, encs
+
+
+def _standalone_mlp(m, x):
+    """Mlp.forward as its own autograd node (module-level API / tests; the model path uses EncoderFn)."""
+    return ops.MlpFn.apply(x, m, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, _w16(m.fc1), _w16(m.fc2),
+                           m.gate_on(x.device) if x.is_cuda else None, torch.is_grad_enabled())
+
+
+def _standalone_attention(m, x, output_qkv):
+    out, qkv = ops.AttentionFn.apply(x, m, m.qkv.weight, m.qkv.bias, m.proj.weight, m.proj.bias, _w16(m.qkv),
+                                     _w16(m.proj), m.gate_on(x.device) if x.is_cuda else None,
+                                     torch.is_grad_enabled())
+    B, N, _ = x.shape
+    outputs = {'output': out}
+    outputs['qkv'] = qkv_views(qkv, B, N, m.num_heads) if output_qkv else None
+    return outputs
+
+
+class PatchEmbed(nn.Module):
+    """timm 0.5.4 PatchEmbed surface: Conv2d(3, D, 16, 16) weights, run as im2row + MFMA GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.flatten = flatten
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = nn.Identity()
+        if img_size != 224 or patch_size != 16 or in_chans != 3:
+            raise NotImplementedError("the patch-embed kernels are built for 3x224x224 images, 16x16 patches")
+
+
+class VisionTransformer(nn.Module):
+    """models/de_vit.py:124-334 (gated ViT / DeiT with dict outputs)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, distilled=False,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., embed_layer=PatchEmbed, norm_layer=None,
+                 act_layer=None, weight_init='', resize_dim=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 2 if distilled else 1
+        self.resize_dim = resize_dim
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        act_layer = act_layer or nn.GELU
+        if representation_size:
+            raise NotImplementedError("representation_size (pre_logits) is not used by any DeViT model")
+
+        self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if distilled else None
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        if drop_rate != 0.:
+            raise NotImplementedError("dropout p > 0 is not on the DeViT hot path (distill_sub.py --drop 0.0)")
+
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]      # de_vit.py:175
+        self.blocks = nn.Sequential(*[
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                  attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, act_layer=act_layer)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.head_dist = None
+        if distilled:
+            self.head_dist = nn.Linear(self.embed_dim, self.num_classes) if num_classes > 0 else nn.Identity()
+        if self.resize_dim is not None:   # registered for checkpoint compatibility (de_vit.py:198-201)
+            self.resize_mlp = nn.Linear(self.embed_dim, self.resize_dim)
+            self.resize_att_mlp = nn.Linear(self.embed_dim, self.resize_dim)
+            self.resize_encoder_mlp = nn.Linear(self.embed_dim, self.resize_dim)
+        self.grad_ready = None      # set by devit_amd.ddp.BucketedGradReducer
+        self.exact_gelu = 0
+        self.init_weights(weight_init)
+
+    # ---- init / bookkeeping identical to the reference (de_vit.py:205-240) ------------------------------
+    def init_weights(self, mode=''):
+        assert mode in ('jax', 'jax_nlhb', 'nlhb', '')
+        if mode.startswith('jax'):
+            raise NotImplementedError("jax weight init is not used by DeViT")
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        if self.dist_token is not None:
+            nn.init.trunc_normal_(self.dist_token, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        self.apply(_init_vit_weights)
+
+    def _init_weights(self, m):
+        _init_vit_weights(m)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'dist_token'}
+
+    def get_classifier(self):
+        return self.head if self.dist_token is None else (self.head, self.head_dist)
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        self.num_classes = num_classes
+        dev = self.cls_token.device
+        self.head = (nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()).to(dev)
+        if self.num_tokens == 2:
+            self.head_dist = (nn.Linear(self.embed_dim, self.num_classes) if num_classes > 0 else nn.Identity()).to(dev)
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def embed(self, x):
+        """patch_embed + cls/dist tokens + pos_embed (de_vit.py:258-264) -> fp32 [B, T, D]."""
+        L.require_device(x)
+        return ops.PatchEmbedFn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token,
+                                      self.dist_token, self.pos_embed, _w16(self.patch_embed.proj), self.grad_ready)
+
+    def _tokens_and_logits(self, x, with_heads):
+        head = self.head if (with_heads and isinstance(self.head, nn.Linear)) else None
+        hd = self.head_dist if (with_heads and isinstance(self.head_dist, nn.Linear)) else None
+        return ops.HeadsFn.apply(x, self.norm.weight, self.norm.bias,
+                                 head.weight if head is not None else None, head.bias if head is not None else None,
+                                 hd.weight if hd is not None else None, hd.bias if hd is not None else None,
+                                 self.num_tokens, self.norm.eps, self.grad_ready)
+
+    def forward_features(self, x, output_qkv=False, output_att=False, output_emb=False, output_encoders=False):
+        out, _ = self._features(x, output_qkv, output_att, output_emb, output_encoders, with_heads=False)
+        return out
+
+    def _features(self, x, output_qkv, output_att, output_emb, output_encoders, with_heads):
+        if self.resize_dim is not None:
+            raise NotImplementedError("resize_dim (--distillation-token) is outside the DEKD hot path")
+        x = self.embed(x)
+        emb = x
+        xo, qkvs, atts, encs = run_blocks(list(self.blocks), x, self.training, output_qkv, output_att, output_encoders,
+                                          grad_ready=self.grad_ready, exact_gelu=self.exact_gelu)
+        depth = len(self.blocks)
+        encoder_outputs = [emb] if output_emb else []
+        encoder_outputs += encs if output_encoders else [None] * depth
+        heads = self._tokens_and_logits(xo, with_heads)
+        tok = heads[0]
+        outputs = {'output': tok[:, 0] if self.dist_token is None else (tok[:, 0], tok[:, 1]),
+                   'qkv': qkvs if output_qkv else [None] * depth,
+                   'attention': atts if output_att else [None] * depth,
+                   'encoder': encoder_outputs}
+        return outputs, heads
+
+    def forward(self, x, distill_token=False, output_qkv=False, output_att=False, output_emb=False,
+                output_encoders=False):
+        outputs, heads = self._features(x, output_qkv, output_att, output_emb, output_encoders, with_heads=True)
+        last_tokens = outputs['output']
+        any_flag = distill_token or output_qkv or output_att or output_emb or output_encoders
+        if self.head_dist is not None:
+            x, x_dist = (heads[1], heads[2]) if len(heads) == 3 else last_tokens     # Identity heads: tokens
+            outputs['output'] = (x, x_dist) if self.training else (x + x_dist) / 2     # de_vit.py:318
+            outputs['last_tokens'] = last_tokens if distill_token else None
+            if any_flag:
+                return outputs
+            return (x, x_dist) if self.training else outputs['output']
+        x = heads[1] if len(heads) >= 2 else last_tokens
+        outputs['output'] = x
+        outputs['last_tokens'] = last_tokens if distill_token else None
+        return outputs if any_flag else x
+
+
+def _init_vit_weights(module, name='', head_bias=0., jax_impl=False):
+    """models/de_vit.py:337-369 as reached from init_weights('') (no names -> heads are NOT zeroed)."""
+    if isinstance(module, nn.Linear):
+        nn.init.trunc_normal_(module.weight, std=.02)
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d)):
+        nn.init.zeros_(module.bias)
+        nn.init.ones_(module.weight)
+
+
+# Geometry table, importable and correct (the reference's models/utils/config.py:1-17 raises NameError and
+# lists 192/3 for `dedeit`; App. D Q1).  `distilled` follows models/deit_vit.py:528-550.
+_LN = partial(nn.LayerNorm, eps=1e-6)
+model_config = {
+    'dedeit': dict(patch_size=16, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=True),
+    'devit': dict(patch_size=16, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=False),
+    'deit_tiny_patch16_224': dict(patch_size=16, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=False),
+    'deit_base_patch16_224': dict(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=False),
+    'deit_tiny_distilled_patch16_224': dict(patch_size=16, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=True),
+    'deit_base_distilled_patch16_224': dict(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=True),
+    'vit_tiny_patch16_224': dict(patch_size=16, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=False),
+    'vit_base_patch16_224': dict(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=False),
+    'vit_large_patch16_224': dict(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True, norm_layer=_LN, distilled=False),
+}
+
+
+def _cfg(**kwargs):
+    return {'url': '', 'num_classes': 1000, 'input_size': (3, 224, 224), 'pool_size': None, 'crop_pct': .9,
+            'interpolation': 'bicubic', 'fixed_input_size': True, 'mean': (0.485, 0.456, 0.406),
+            'std': (0.229, 0.224, 0.225), 'first_conv': 'patch_embed.proj', 'classifier': 'head', **kwargs}
+
+
+def _make(name):
+    def fn(pretrained=False, pretrained_path=None, **kwargs):
+        model = VisionTransformer(**{**model_config[name], **kwargs})
+        model.default_cfg = _cfg()
+        if pretrained_path is not None and pretrained:
+            ckpt = torch.load(pretrained_path, map_location='cpu')
+            model.load_state_dict(ckpt['model'] if 'model' in ckpt else ckpt)
+        return model
+    fn.__name__ = name
+    fn.__doc__ = f"{name}: registered like models/de_vit.py:495-513 / models/deit_vit.py:457-525 (dict-API class)."
+    return register_model(fn)
+
+
+dedeit = _make('dedeit')
+devit = _make('devit')
+for _n in list(model_config):
+    if _n not in ('dedeit', 'devit'):
+        globals()[_n] = _make(_n)

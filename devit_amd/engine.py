@@ -1,0 +1,104 @@
+"""Step loops with the reference's names and semantics (engine.py), hosted on the HIP path.
+
+  distill_forward   : engine.py:68-106 (student train forward, teacher eval forward, DEKD losses)
+  train_1epoch_qkv  : engine.py:48-140
+  evaluate          : engine.py:17-45
+The five `.item()` host syncs + `cuda.synchronize()` per step of the reference (engine.py:108-117,130) are
+kept for logging parity in train_1epoch_qkv, but only every `print_freq` steps.
+"""
+import math
+import sys
+
+import torch
+
+from . import de_vit, losses
+
+
+def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0,
+                    criterion=None, dp_scales="draw"):
+    """One DEKD forward.  Returns dict(loss, cls_loss, q_loss, k_loss, v_loss, logits, teacher_logits)."""
+    vit = model.module if hasattr(model, "module") else model
+    if dp_scales != "draw":   # explicit DropPath masks (parity tests)
+        outputs = _forward_with_dp(vit, samples, dp_scales)
+    else:
+        outputs = model(samples, output_qkv=True)                                   # engine.py:70
+    logits, qkvs = outputs['output'], outputs['qkv']
+    with torch.no_grad():
+        teacher_outputs = teacher_model(samples, output_qkv=True)                   # engine.py:73-76
+    teacher_logits, teacher_qkvs = teacher_outputs['output'], teacher_outputs['qkv']
+    if criterion is None:
+        criterion = losses.DistillLoss(losses.SoftTargetCrossEntropy(), kind, alpha, tau)
+    cls_loss = criterion(outputs=logits, teacher_outputs=teacher_logits, labels=targets)   # :79
+    tl, sl = len(teacher_qkvs), len(qkvs)
+    assert tl % sl == 0, 'The number of student layer can not be divisible by the number of teacher layer'
+    q_loss, k_loss, v_loss = losses.relation_losses_packed(qkvs[sl // 2 - 1], teacher_qkvs[tl // 2 - 1])  # :91-100
+    q_loss, k_loss, v_loss = q_loss / sl, k_loss / sl, v_loss / sl                  # :102-104
+    loss = cls_loss + float(gama[0]) * q_loss + float(gama[1]) * k_loss + float(gama[2]) * v_loss   # :105-106
+    return dict(loss=loss, cls_loss=cls_loss, q_loss=q_loss, k_loss=k_loss, v_loss=v_loss, logits=logits,
+                teacher_logits=teacher_logits)
+
+
+def _forward_with_dp(vit, samples, dp_scales):
+    x = vit.embed(samples)
+    xo, qkvs, _, _ = de_vit.run_blocks(list(vit.blocks), x, vit.training, True, False, False,
+                                       grad_ready=vit.grad_ready, dp_scales=dp_scales)
+    heads = vit._tokens_and_logits(xo, True)
+    return {'output': (heads[1], heads[2]) if vit.training else (heads[1] + heads[2]) / 2, 'qkv': qkvs}
+
+
+def train_1epoch_qkv(model, teacher_model, criterion, data_loader, optimizer, device, epoch, loss_scaler, log, args,
+                     max_norm=0, model_ema=None, mixup_fn=None, print_freq=10):
+    """engine.py:48-140.  `loss_scaler(loss, optimizer, clip_grad=, parameters=)` keeps timm NativeScaler's call
+    shape; bf16 needs no loss scaling, so devit_amd.optim.StepRunner is the usual object here."""
+    from .utils import MetricLogger, SmoothedValue
+    model.train(True)
+    metric_logger = MetricLogger(delimiter="  ")
+    for name in ('lr', 'cls_loss', 'q_loss', 'k_loss', 'v_loss'):
+        metric_logger.add_meter(name, SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    header = 'Epoch: [{}]'.format(epoch)
+    step = 0
+    for samples, targets in metric_logger.log_every(data_loader, print_freq, header):
+        samples = samples.to(device, non_blocking=True)
+        targets = targets.to(device, non_blocking=True)
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)
+        out = distill_forward(model, teacher_model, samples, targets, gama=args.gama, criterion=criterion)
+        loss = out['loss']
+        log_now = (step % print_freq == 0)
+        if log_now:
+            loss_value = loss.item()
+            if not math.isfinite(loss_value):                                        # engine.py:119-121
+                print("Loss is {}, stopping training".format(loss_value))
+                sys.exit(1)
+            metric_logger.update(cls_loss=out['cls_loss'].item(), q_loss=out['q_loss'].item(),
+                                 k_loss=out['k_loss'].item(), v_loss=out['v_loss'].item(), loss=loss_value)
+        optimizer.zero_grad()
+        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters())
+        if model_ema is not None:
+            model_ema.update(model)
+        if log_now:
+            metric_logger.update(lr=optimizer.param_groups[0]["lr"])
+        step += 1
+    metric_logger.synchronize_between_processes()
+    if log is not None:
+        log.info(f"Averaged stats: {metric_logger}")
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def evaluate(data_loader, model, device):
+    """engine.py:17-45: eval forward, CE, top-1 / top-5."""
+    from .utils import MetricLogger, accuracy
+    metric_logger = MetricLogger(delimiter="  ")
+    model.eval()
+    for images, target in metric_logger.log_every(data_loader, 10, 'Test:'):
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        output = model(images)
+        loss = losses.DistillLoss(losses.SoftTargetCrossEntropy(), 'none', 0., 1.)(output, None, target)
+        acc1, acc5 = accuracy(output, target, topk=(1, min(5, output.shape[1])))
+        metric_logger.update(loss=loss.item())
+        metric_logger.meters['acc1'].update(acc1.item(), n=images.shape[0])
+        metric_logger.meters['acc5'].update(acc5.item(), n=images.shape[0])
+    metric_logger.synchronize_between_processes()
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

@@ -1,0 +1,117 @@
+"""DEKD losses with the reference's API (utils/losses.py), computed by libdevit_hip.so.
+
+  DistillLoss(base_criterion, distillation_type, alpha, tau)(outputs, teacher_outputs, labels)   :122-177
+  feature_relation_loss(teacher_feature, student_feature)                                        :307-328
+  relation_losses_packed(student_qkv, teacher_qkv)   -- the three q/k/v losses of engine.py:95 in one node
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+
+class SoftTargetCrossEntropy(nn.Module):
+    """timm.loss.SoftTargetCrossEntropy (distill_sub.py:348): sum(-t * log_softmax(x)).mean().
+    A marker class: DistillLoss fuses it with the distillation term in one kernel."""
+
+    def forward(self, x, target):
+        zero = torch.zeros_like(x)
+        return ops.ClsDistillLossFn.apply(x, x, zero, target, "none", 0.0, 1.0)
+
+
+class DistillLoss(nn.Module):
+    """utils/losses.py:122-177.  `labels` are the soft [B, C] targets produced by Mixup (engine.py:66); hard
+    int64 labels are expanded to one-hot rows (== nn.CrossEntropyLoss, distill_sub.py:352)."""
+
+    def __init__(self, base_criterion, distillation_type, alpha, tau):
+        super().__init__()
+        assert distillation_type in ['none', 'soft', 'hard']
+        if not isinstance(base_criterion, (SoftTargetCrossEntropy, nn.CrossEntropyLoss)):
+            raise NotImplementedError("DistillLoss is fused for SoftTargetCrossEntropy / CrossEntropyLoss base criteria")
+        self.base_criterion = base_criterion
+        self.distillation_type = distillation_type
+        self.alpha = alpha
+        self.tau = tau
+
+    def forward(self, outputs, teacher_outputs, labels):
+        if not isinstance(outputs, torch.Tensor):
+            outputs, outputs_kd = outputs         # (cls head, dist head), utils/losses.py:164-167
+        else:
+            outputs_kd = outputs
+        if labels.dtype in (torch.int64, torch.int32):
+            labels = torch.nn.functional.one_hot(labels.long(), outputs.shape[1]).to(outputs.dtype)
+        return ops.ClsDistillLossFn.apply(outputs, outputs_kd, teacher_outputs, labels, self.distillation_type,
+                                          float(self.alpha), float(self.tau))
+
+
+def _packed_of(t):
+    p = getattr(t, "_devit_packed", None)
+    return p
+
+
+def relation_losses_packed(student_qkv, teacher_qkv):
+    """(q_loss, k_loss, v_loss) for one layer pair.  Arguments are the (q, k, v) tuples returned by the models
+    with output_qkv=True (strided views of the packed qkv GEMM output)."""
+    sp, tp = _packed_of(student_qkv[0]), _packed_of(teacher_qkv[0])
+    if sp is None or tp is None:
+        return tuple(feature_relation_loss(tv, sv) for sv, tv in zip(student_qkv, teacher_qkv))
+    (s_buf, B, N, Hs), (t_buf, Bt, Nt, Ht) = sp, tp
+    assert (B, N) == (Bt, Nt)
+    hd_s, hd_t = s_buf.shape[1] // (3 * Hs), t_buf.shape[1] // (3 * Ht)
+    losses = ops.RelationLossFn.apply(s_buf, t_buf.detach(), B, N, hd_s, hd_t)
+    return losses[0], losses[1], losses[2]
+
+
+def _repack(feature):
+    """[B, H, N, hd] (any strides) -> packed bf16 [pad(B*N) + 128, 3*H*hd] with the feature in every component."""
+    B, H, N, hd = feature.shape
+    D = H * hd
+    buf = ops.rows_alloc(B * N, 3 * D, torch.bfloat16, feature.device, extra=128)
+    f = feature.permute(0, 2, 1, 3).reshape(B * N, D)
+    return buf, f, (B, N, H, hd, D)
+
+
+class _RepackFn(torch.autograd.Function):
+    """Differentiable copy of one [B,H,N,hd] feature into component 0 of a zeroed packed buffer."""
+
+    @staticmethod
+    def forward(ctx, feature):
+        buf, f, meta = _repack(feature)
+        buf[: f.shape[0], : meta[4]] = f.to(torch.bfloat16)
+        buf[: f.shape[0], meta[4]:].zero_()
+        ctx.meta = meta
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, H, hd, D = ctx.meta
+        return g[: B * N, :D].reshape(B, N, H, hd).permute(0, 2, 1, 3).float()
+
+
+def feature_relation_loss(teacher_feature, student_feature):
+    """utils/losses.py:307-328 (note the argument order).  Generic entry: accepts any [B, H, N, hd] tensors;
+    the engine uses relation_losses_packed, which reads the qkv GEMM output in place."""
+    L.require_device(student_feature)
+    B, Hs, N, hd_s = student_feature.shape
+    _, Ht, _, hd_t = teacher_feature.shape
+    s_buf = _RepackFn.apply(student_feature)
+    with torch.no_grad():
+        t_buf = _RepackFn.apply(teacher_feature)
+    losses = ops.RelationLossFn.apply(s_buf, t_buf, B, N, hd_s, hd_t)
+    return losses[0]
+
+
+class LabelSmoothingCrossEntropy(nn.Module):
+    """utils/losses.py:10-34; expressed through the fused kernel with smoothed one-hot targets."""
+
+    def __init__(self, smoothing=0.1):
+        super().__init__()
+        assert smoothing < 1.0
+        self.smoothing = smoothing
+        self.confidence = 1. - smoothing
+
+    def forward(self, x, target):
+        C = x.shape[-1]
+        soft = torch.full_like(x, self.smoothing / C).scatter_(1, target[:, None], self.confidence + self.smoothing / C)
+        return ops.ClsDistillLossFn.apply(x, x, torch.zeros_like(x), soft, "none", 0.0, 1.0)

@@ -1,0 +1,578 @@
+"""Tensor-level wrappers over the C ABI (include/devit_hip.h) and the autograd Functions built on them.
+
+PyTorch is plumbing here: it owns device memory and streams, autograd stitches the hand-written
+forward/backward kernel sequences together.  No arithmetic of the hot path runs in torch ops.
+
+Layout conventions
+  * token rows: M = B * N; every bf16 activation that feeds a GEMM lives in a buffer whose row count is
+    padded to a multiple of 128 with ZERO pad rows (`rows_alloc`): the GEMM tiles are 128 rows tall and
+    the weight-gradient GEMMs reduce over the padded row count.
+  * residual stream: fp32 [B, N, D]; branch activations / branch gradients: bf16.
+  * weight gradients are ACCUMULATED straight into `param.grad` (fp32, allocated zero on first use), the
+    way DDP "main_grad" fusions do; `backward` returns None for parameters and reports finished blocks
+    through `grad_ready` callbacks (devit_amd/ddp.py hooks its bucket all-reduce there).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import call, ptr, stream_ptr
+
+BF16, F32 = torch.bfloat16, torch.float32
+ROW_TILE = 128
+
+
+def pad_rows(m):
+    return (m + ROW_TILE - 1) // ROW_TILE * ROW_TILE
+
+
+def rows_alloc(m, cols, dtype, device, extra=0):
+    """[pad_rows(m) + extra, cols] buffer whose rows >= m are zero."""
+    mp = pad_rows(m) + extra
+    t = torch.empty((mp, cols), dtype=dtype, device=device)
+    if mp > m:
+        t[m:].zero_()
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(device, nbytes):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 8 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+# thin wrappers
+# ----------------------------------------------------------------------------------------------
+def gemm(a, lda, a_km, b, ldb, b_km, M, N, K, *, kind, out, ldc, bias=None, colscale=None, aux=None, aux_in=None,
+         res=None, rowscale=None, rows_per_scale=0, pos=None, patch_tokens=0, extra_tokens=0, exact_gelu=0, batch=1,
+         a_bs=0, b_bs=0, out_bs=0, m_valid=0, split_k=1, a_group=0, a_skip=0, b_group=0, b_skip=0):
+    A = L.Operand(a.data_ptr(), lda, a_km, a_group, a_skip, a_bs)
+    Bo = L.Operand(b.data_ptr(), ldb, b_km, b_group, b_skip, b_bs)
+    ep = L.Epilogue(kind, out.data_ptr(), ldc, _p(bias), _p(colscale), _p(aux), _p(aux_in), _p(res), _p(rowscale),
+                    rows_per_scale, _p(pos), patch_tokens, extra_tokens, exact_gelu, out_bs, m_valid)
+    call("devit_gemm_bf16", C.byref(A), C.byref(Bo), M, N, K, batch, split_k, C.byref(ep), stream_ptr())
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def split_k_for(out_rows, out_cols, ksteps, target_wgs=512):
+    tiles = (out_rows // 128) * (out_cols // 128)
+    return max(1, min(ksteps, (target_wgs + tiles - 1) // tiles))
+
+
+def linear_fwd(x, w, bias, M, *, out, kind=L.EPI_STORE_BF16, **kw):
+    """out[M, N] = x[Mp, K] @ w[N, K]^T (+ epilogue).  x is a padded bf16 buffer."""
+    N, K = w.shape
+    gemm(x, x.stride(0), 0, w, K, 0, pad_rows(M), N, K, kind=kind, out=out, ldc=out.stride(0), bias=bias, m_valid=M,
+         **kw)
+
+
+def linear_dgrad(dy, w, M, *, out, kind=L.EPI_STORE_BF16, **kw):
+    """out[M, K] = dy[Mp, N] @ w[N, K]   (w read k-major)."""
+    N, K = w.shape
+    gemm(dy, dy.stride(0), 0, w, K, 1, pad_rows(M), K, N, kind=kind, out=out, ldc=out.stride(0), m_valid=M, **kw)
+
+
+def linear_wgrad(dy, x, w_grad, b_grad, M, **kw):
+    """w_grad[N, K] += dy[Mp, N]^T @ x[Mp, K];  b_grad[N] += colsum(dy).  Pad rows of dy are zero."""
+    N, K = w_grad.shape
+    mp = pad_rows(M)
+    gemm(dy, dy.stride(0), 1, x, x.stride(0), 1, N, K, mp, kind=L.EPI_ATOMIC_F32, out=w_grad, ldc=K,
+         split_k=split_k_for(N, K, mp // 64), **kw)
+    if b_grad is not None:
+        colsum(dy, M, N, b_grad, accumulate=True)
+
+
+def colsum(y, M, N, out, accumulate, row_group=0, row_skip=0):
+    nbytes = 64 * N * 4
+    ws = workspace(y.device, nbytes)
+    call("devit_colsum_bf16", ptr(y), M, N, y.stride(0), row_group, row_skip, ptr(out), int(accumulate), ptr(ws),
+         ws.numel(), stream_ptr())
+
+
+def layernorm_fwd(x2d, rows, D, gamma, beta, eps, *, y_bf16=None, y_f32=None, mean=None, rstd=None, in_group=0,
+                  in_stride=0):
+    call("devit_layernorm_fwd", ptr(x2d), rows, D, in_group, in_stride, ptr(gamma), ptr(beta), eps, ptr(y_bf16),
+         ptr(y_f32), ptr(mean), ptr(rstd), stream_ptr())
+
+
+def layernorm_bwd(dy, dy_is_f32, x2d, rows, D, mean, rstd, gamma, dres, dx, dx_bf16, rowscale, rows_per_scale, dgamma,
+                  dbeta, in_group=0, in_stride=0):
+    nbytes = L.load().devit_layernorm_bwd_workspace(rows, D)
+    ws = workspace(x2d.device, nbytes)
+    call("devit_layernorm_bwd", ptr(dy), int(dy_is_f32), ptr(x2d), rows, D, in_group, in_stride, ptr(mean), ptr(rstd),
+         ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(rowscale), rows_per_scale, ptr(dgamma), ptr(dbeta), 1,
+         ptr(ws), ws.numel(), stream_ptr())
+
+
+def cast_bf16(src, dst=None):
+    src = src.contiguous()
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    call("devit_cast_bf16", ptr(src), ptr(dst), src.numel(), stream_ptr())
+    return dst
+
+
+def grad_buf(p):
+    """fp32 accumulation buffer of a parameter (== param.grad, zero-initialised on first use)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+def sgemm_small(A, sam, sak, Bm, sbn, sbk, bias, Cm, ldc, M, N, K, alpha=1.0, accumulate=False):
+    call("devit_sgemm_small", ptr(A), sam, sak, ptr(Bm), sbn, sbk, ptr(bias), ptr(Cm), ldc, M, N, K, alpha,
+         int(accumulate), stream_ptr())
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder blocks (models/de_vit.py:103-121 x depth) as ONE autograd node
+# ----------------------------------------------------------------------------------------------
+class BlockParams:
+    """fp32 parameters + cached bf16 GEMM copies of one Block (see de_vit.Block)."""
+    __slots__ = ("n1w", "n1b", "qkv_w", "qkv_b", "proj_w", "proj_b", "n2w", "n2b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                 "qkv_w16", "proj_w16", "fc1_w16", "fc2_w16", "num_heads", "head_gate", "neuron_gate", "dp_prob",
+                 "module")
+
+    def all_params(self):
+        return [self.n1w, self.n1b, self.qkv_w, self.qkv_b, self.proj_w, self.proj_b, self.n2w, self.n2b, self.fc1_w,
+                self.fc1_b, self.fc2_w, self.fc2_b]
+
+
+class EncoderCfg:
+    """Non-tensor arguments of EncoderFn."""
+
+    def __init__(self, blocks, training, dp_scales, want_qkv, want_att, want_enc, eps=1e-6, exact_gelu=0,
+                 grad_ready=None):
+        self.blocks, self.training, self.dp_scales = blocks, training, dp_scales
+        self.want_qkv, self.want_att, self.want_enc = want_qkv, want_att, want_enc
+        self.eps, self.exact_gelu, self.grad_ready = eps, exact_gelu, grad_ready
+
+
+def _block_forward(x, bp, dp, cfg, need_grad, want_att):
+    """x: fp32 [B, N, D] contiguous.  Returns (x_out, saved dict)."""
+    B, N, D = x.shape
+    M, H, dev = B * N, bp.num_heads, x.device
+    x2 = x.view(M, D)
+    s = {}
+    ln1 = rows_alloc(M, D, BF16, dev)
+    mean1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
+    rstd1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
+    layernorm_fwd(x2, M, D, bp.n1w, bp.n1b, cfg.eps, y_bf16=ln1, mean=mean1, rstd=rstd1)
+    qkv = rows_alloc(M, 3 * D, BF16, dev, extra=128)
+    linear_fwd(ln1, bp.qkv_w16, bp.qkv_b, M, out=qkv)
+    attn_o = rows_alloc(M, D, BF16, dev)
+    lse = torch.empty((B, H, N), dtype=F32, device=dev) if need_grad else None
+    call("devit_attn_fwd", ptr(qkv), ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, N, H, D // H, (D // H) ** -0.5,
+         stream_ptr())
+    x1 = torch.empty((B, N, D), dtype=F32, device=dev)
+    att = torch.empty((M, D), dtype=BF16, device=dev) if want_att else None
+    dp1, dp2 = dp if dp is not None else (None, None)
+    linear_fwd(attn_o, bp.proj_w16, bp.proj_b, M, out=x1.view(M, D), kind=L.EPI_RESIDUAL_F32, res=x2, rowscale=dp1,
+               rows_per_scale=N, aux=att)
+    ln2 = rows_alloc(M, D, BF16, dev)
+    mean2 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
+    rstd2 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
+    layernorm_fwd(x1.view(M, D), M, D, bp.n2w, bp.n2b, cfg.eps, y_bf16=ln2, mean=mean2, rstd=rstd2)
+    Hd = bp.fc1_w.shape[0]
+    h = rows_alloc(M, Hd, BF16, dev)
+    h_pre = rows_alloc(M, Hd, BF16, dev) if need_grad else None
+    linear_fwd(ln2, bp.fc1_w16, bp.fc1_b, M, out=h, kind=L.EPI_GELU_BF16, colscale=bp.neuron_gate, aux=h_pre,
+               exact_gelu=cfg.exact_gelu)
+    x2o = torch.empty((B, N, D), dtype=F32, device=dev)
+    linear_fwd(h, bp.fc2_w16, bp.fc2_b, M, out=x2o.view(M, D), kind=L.EPI_RESIDUAL_F32, res=x1.view(M, D), rowscale=dp2,
+               rows_per_scale=N)
+    if bp.module is not None:  # shrink contract (core/imp_rank.py:31,108): post-mask values
+        bp.module.mlp.neuron_output = h[:M].view(B, N, Hd)
+        bp.module.attn.head_output = attn_o[:M].view(B, N, H, D // H)
+    if need_grad:
+        s = dict(x=x, ln1=ln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn_o=attn_o, lse=lse, x1=x1, ln2=ln2, mean2=mean2,
+                 rstd2=rstd2, h=h, h_pre=h_pre, dp1=dp1, dp2=dp2)
+    return x2o, qkv, att, s
+
+
+def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g):
+    """dx: fp32 [B,N,D] grad of the block output; g2: bf16 [Mp, D] = bf16(dp2 * dx).
+    Returns (dx_in fp32 [B,N,D], g_prev bf16 [Mp,D] = bf16(prev_dp2 * dx_in) or None)."""
+    B, N, D = dx.shape
+    M, H, dev = B * N, bp.num_heads, dx.device
+    Hd = bp.fc1_w.shape[0]
+    # ---- MLP branch: x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2)))
+    dh_pre = rows_alloc(M, Hd, BF16, dev)
+    linear_dgrad(g2, bp.fc2_w16, M, out=dh_pre, kind=L.EPI_DGELU_BF16, colscale=bp.neuron_gate, aux_in=s["h_pre"],
+                 exact_gelu=cfg.exact_gelu)
+    linear_wgrad(g2, s["h"], grad_buf(bp.fc2_w), grad_buf(bp.fc2_b), M)
+    dln2 = rows_alloc(M, D, BF16, dev)
+    linear_dgrad(dh_pre, bp.fc1_w16, M, out=dln2)
+    linear_wgrad(dh_pre, s["ln2"], grad_buf(bp.fc1_w), grad_buf(bp.fc1_b), M)
+    dx1 = torch.empty((B, N, D), dtype=F32, device=dev)
+    g1 = rows_alloc(M, D, BF16, dev)
+    layernorm_bwd(dln2, False, s["x1"].view(M, D), M, D, s["mean2"], s["rstd2"], bp.n2w, dx.view(M, D), dx1.view(M, D),
+                  g1, s["dp1"], N, grad_buf(bp.n2w), grad_buf(bp.n2b))
+    # ---- attention branch: x1 = x + dp1 * proj(gate * attn(qkv(ln1)))
+    if datt is not None:  # gradient flowing into the exposed 'attention' output (pre-residual, post-proj)
+        g1 = g1 + _pad_like(datt, g1)
+    dattn = rows_alloc(M, D, BF16, dev)
+    linear_dgrad(g1, bp.proj_w16, M, out=dattn)
+    linear_wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), grad_buf(bp.proj_b), M)
+    dqkv = rows_alloc(M, 3 * D, BF16, dev)
+    call("devit_attn_bwd", ptr(s["qkv"]), ptr(s["attn_o"]), ptr(dattn), ptr(s["lse"]), ptr(bp.head_gate),
+         ptr(dqkv_add), ptr(dqkv), B, N, H, D // H, (D // H) ** -0.5, stream_ptr())
+    dln1 = rows_alloc(M, D, BF16, dev)
+    linear_dgrad(dqkv, bp.qkv_w16, M, out=dln1)
+    linear_wgrad(dqkv, s["ln1"], grad_buf(bp.qkv_w), grad_buf(bp.qkv_b), M)
+    dx0 = torch.empty((B, N, D), dtype=F32, device=dev)
+    g_prev = rows_alloc(M, D, BF16, dev) if want_prev_g else None
+    layernorm_bwd(dln1, False, s["x"].view(M, D), M, D, s["mean1"], s["rstd1"], bp.n1w, dx1.view(M, D), dx0.view(M, D),
+                  g_prev, prev_dp2, N, grad_buf(bp.n1w), grad_buf(bp.n1b))
+    return dx0, g_prev
+
+
+def _pad_like(t2d, ref):
+    out = torch.zeros_like(ref)
+    out[: t2d.shape[0]] = t2d.to(ref.dtype)
+    return out
+
+
+def scale_cast(dx, rowscale, N):
+    B, _, D = dx.shape
+    M = B * N
+    g = rows_alloc(M, D, BF16, dx.device)
+    call("devit_scale_cast_bf16", ptr(dx), ptr(g), ptr(rowscale), N, M, D, stream_ptr())
+    return g
+
+
+class EncoderFn(torch.autograd.Function):
+    """x -> blocks[0..n) -> (x_out, [qkv_i bf16 packed ...], [att_i ...], [enc_i ...])."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        L.require_device(x)
+        x = x.contiguous()
+        need_grad = cfg.grad_enabled and (x.requires_grad or any(p.requires_grad for p in params))
+        saved, qkvs, atts, encs = [], [], [], []
+        for i, bp in enumerate(cfg.blocks):
+            dp = cfg.dp_scales[i] if cfg.dp_scales is not None else None
+            x, qkv, att, s = _block_forward(x, bp, dp, cfg, need_grad, cfg.want_att)
+            saved.append(s)
+            if cfg.want_qkv:
+                qkvs.append(qkv)
+            if cfg.want_att:
+                atts.append(att)
+            if cfg.want_enc:
+                encs.append(x.clone() if i == len(cfg.blocks) - 1 else x)
+        ctx.cfg, ctx.saved, ctx.need_grad = cfg, saved, need_grad
+        ctx.counts = (len(qkvs), len(atts), len(encs))
+        return (x,) + tuple(qkvs) + tuple(atts) + tuple(encs)
+
+    @staticmethod
+    def backward(ctx, dx, *dothers):
+        cfg, saved = ctx.cfg, ctx.saved
+        if not ctx.need_grad:
+            raise L.DevitError("EncoderFn.backward called but the forward ran without grad bookkeeping")
+        nq, na, ne = ctx.counts
+        dqkvs, datts, dencs = dothers[:nq], dothers[nq:nq + na], dothers[nq + na:]
+        nb = len(cfg.blocks)
+        B, N, D = saved[0]["x"].shape
+        if dx is None:
+            dx = torch.zeros((B, N, D), dtype=F32, device=saved[0]["x"].device)
+        dx = dx.contiguous()
+        if ne and dencs[nb - 1] is not None:
+            dx = dx + dencs[nb - 1]
+        g = scale_cast(dx, saved[nb - 1]["dp2"], N)
+        for i in range(nb - 1, -1, -1):
+            bp = cfg.blocks[i]
+            dq = dqkvs[i] if nq else None
+            if dq is not None:
+                dq = dq.contiguous()
+            da = datts[i] if na else None
+            prev_dp2 = saved[i - 1]["dp2"] if i > 0 else None
+            extra = dencs[i - 1] if (ne and i > 0 and dencs[i - 1] is not None) else None
+            dx, g = _block_backward(dx, g, saved[i], bp, cfg, dq, da, prev_dp2, want_prev_g=(i > 0 and extra is None))
+            if extra is not None:
+                dx = dx + extra
+                g = scale_cast(dx, prev_dp2, N)
+            saved[i] = None
+            if cfg.grad_ready is not None:
+                cfg.grad_ready(bp.all_params())
+        return (dx, None) + (None,) * (12 * nb)
+
+
+# ----------------------------------------------------------------------------------------------
+# patch embedding + token assembly (models/de_vit.py:258-264)
+# ----------------------------------------------------------------------------------------------
+class PatchEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, proj_w, proj_b, cls_token, dist_token, pos_embed, w16, grad_ready):
+        L.require_device(img)
+        img = img.contiguous().float()
+        B = img.shape[0]
+        D = proj_w.shape[0]
+        ntok = 2 if dist_token is not None else 1
+        T = 196 + ntok
+        M = B * 196
+        rows = rows_alloc(M, 768, BF16, img.device)
+        call("devit_im2row_bf16", ptr(img), ptr(rows), B, 3, 224, 224, 16, stream_ptr())
+        x = torch.empty((B, T, D), dtype=F32, device=img.device)
+        gemm(rows, 768, 0, w16, 768, 0, pad_rows(M), D, 768, kind=L.EPI_PATCH_F32, out=x, ldc=D, bias=proj_b,
+             pos=pos_embed, patch_tokens=196, extra_tokens=ntok, m_valid=M)
+        call("devit_embed_tokens", ptr(cls_token), ptr(dist_token), ptr(pos_embed), ptr(x), B, T, D, stream_ptr())
+        ctx.rows, ctx.dims = rows, (B, T, D, ntok)
+        ctx.params = (proj_w, proj_b, cls_token, dist_token, pos_embed)
+        ctx.grad_ready = grad_ready
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, T, D, ntok = ctx.dims
+        proj_w, proj_b, cls_token, dist_token, pos_embed = ctx.params
+        dx = dx.contiguous()
+        dev = dx.device
+        # bf16 copy of dx with pad rows (the wgrad reduces over padded patch rows; skipped rows map past the end)
+        dxb = rows_alloc(B * T, D, BF16, dev, extra=128)
+        dpos = torch.empty((T, D), dtype=F32, device=dev)
+        dcls = torch.empty(D, dtype=F32, device=dev)
+        ddist = torch.empty(D, dtype=F32, device=dev) if ntok == 2 else None
+        dbias = torch.empty(D, dtype=F32, device=dev)
+        call("devit_embed_bwd", ptr(dx), B, T, D, ntok, ptr(dpos), ptr(dcls), ptr(ddist), ptr(dbias), ptr(dxb), 0,
+             stream_ptr())
+        grad_buf(pos_embed).view(T, D).add_(dpos)
+        grad_buf(cls_token).view(D).add_(dcls)
+        if ntok == 2:
+            grad_buf(dist_token).view(D).add_(ddist)
+        grad_buf(proj_b).add_(dbias)
+        # dW[D, 768] += dx_patch^T @ rows ; reduction row r=(b,t) lives at physical row r + ntok*(r/196 + 1)
+        M = B * 196
+        mp = pad_rows(M)
+        gemm(dxb, D, 1, ctx.rows, 768, 1, D, 768, mp, kind=L.EPI_ATOMIC_F32, out=grad_buf(proj_w), ldc=768,
+             split_k=split_k_for(D, 768, mp // 64), a_group=196, a_skip=ntok)
+        if ctx.grad_ready is not None:
+            ctx.grad_ready([p for p in ctx.params if p is not None])
+        return (None,) * 8
+
+
+# ----------------------------------------------------------------------------------------------
+# final norm on the cls/dist rows + classifier heads (models/de_vit.py:286-288,316-318)
+# ----------------------------------------------------------------------------------------------
+class HeadsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, head_w, head_b, headd_w, headd_b, ntok, eps, grad_ready):
+        L.require_device(x)
+        x = x.contiguous()
+        B, T, D = x.shape
+        rows = B * ntok
+        dev = x.device
+        tok = torch.empty((B, ntok, D), dtype=F32, device=dev)
+        mean = torch.empty(rows, dtype=F32, device=dev)
+        rstd = torch.empty(rows, dtype=F32, device=dev)
+        layernorm_fwd(x.view(B * T, D), rows, D, norm_w, norm_b, eps, y_f32=tok, mean=mean, rstd=rstd, in_group=ntok,
+                      in_stride=T)
+        outs = [tok]
+        if head_w is not None:
+            Cn = head_w.shape[0]
+            lo = torch.empty((B, Cn), dtype=F32, device=dev)
+            sgemm_small(tok, ntok * D, 1, head_w, D, 1, head_b, lo, Cn, B, Cn, D)
+            outs.append(lo)
+            if ntok == 2 and headd_w is not None:
+                lk = torch.empty((B, Cn), dtype=F32, device=dev)
+                sgemm_small(tok[:, 1], ntok * D, 1, headd_w, D, 1, headd_b, lk, Cn, B, Cn, D)
+                outs.append(lk)
+        ctx.save = (x, tok, mean, rstd)
+        ctx.params = (norm_w, norm_b, head_w, head_b, headd_w, headd_b)
+        ctx.meta = (B, T, D, ntok, eps, grad_ready)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dtok, dlo=None, dlk=None):
+        x, tok, mean, rstd = ctx.save
+        norm_w, norm_b, head_w, head_b, headd_w, headd_b = ctx.params
+        B, T, D, ntok, eps, grad_ready = ctx.meta
+        dev = x.device
+        dt = torch.zeros((B, ntok, D), dtype=F32, device=dev) if dtok is None else dtok.contiguous().clone()
+        for j, (dl, w, b) in enumerate(((dlo, head_w, head_b), (dlk, headd_w, headd_b))):
+            if dl is None or w is None:
+                continue
+            dl = dl.contiguous()
+            Cn = w.shape[0]
+            # dtok_j[B, D] += dl[B, C] @ w[C, D]
+            sgemm_small(dl, Cn, 1, w, 1, D, None, dt[:, j], ntok * D, B, D, Cn, accumulate=True)
+            # dw[C, D] += dl^T @ tok_j ; db += colsum(dl)
+            sgemm_small(dl, 1, Cn, tok[:, j], 1, ntok * D, None, grad_buf(w), D, Cn, D, B, accumulate=True)
+            ones = torch.ones(1, dtype=F32, device=dev)
+            sgemm_small(dl, 1, Cn, ones, 0, 0, None, grad_buf(b), 1, Cn, 1, B, accumulate=True)
+        dx = torch.zeros((B, T, D), dtype=F32, device=dev)
+        layernorm_bwd(dt, True, x.view(B * T, D), B * ntok, D, mean, rstd, norm_w, None, dx.view(B * T, D), None, None,
+                      0, grad_buf(norm_w), grad_buf(norm_b), in_group=ntok, in_stride=T)
+        if grad_ready is not None:
+            grad_ready([p for p in ctx.params if p is not None])
+        return (dx,) + (None,) * 9
+
+
+# ----------------------------------------------------------------------------------------------
+# stand-alone Mlp / Attention nodes (module-level API of models/de_vit.py:21-87; the model path
+# runs whole blocks through EncoderFn)
+# ----------------------------------------------------------------------------------------------
+def _to_rows_bf16(x):
+    B, N, D = x.shape
+    M = B * N
+    buf = rows_alloc(M, D, BF16, x.device)
+    call("devit_scale_cast_bf16", ptr(x.contiguous().float()), ptr(buf), None, 0, M, D, stream_ptr())
+    return buf
+
+
+class MlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, w1, b1, w2, b2, w1_16, w2_16, gate, grad_enabled):
+        L.require_device(x)
+        B, N, D = x.shape
+        M, dev, Hd, Do = B * N, x.device, w1.shape[0], w2.shape[0]
+        xb = _to_rows_bf16(x)
+        need = grad_enabled and (x.requires_grad or w1.requires_grad)
+        h = rows_alloc(M, Hd, BF16, dev)
+        h_pre = rows_alloc(M, Hd, BF16, dev) if need else None
+        linear_fwd(xb, w1_16, b1, M, out=h, kind=L.EPI_GELU_BF16, colscale=gate, aux=h_pre, exact_gelu=0)
+        y = torch.empty((B, N, Do), dtype=F32, device=dev)
+        linear_fwd(h, w2_16, b2, M, out=y.view(M, Do), kind=L.EPI_STORE_F32)
+        module.neuron_output = h[:M].view(B, N, Hd)
+        ctx.s = (xb, h, h_pre, gate, w1, b1, w2, b2, w1_16, w2_16, (B, N, D))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, h, h_pre, gate, w1, b1, w2, b2, w1_16, w2_16, (B, N, D) = ctx.s
+        M, dev, Hd = B * N, dy.device, w1.shape[0]
+        g = _to_rows_bf16(dy)
+        dh = rows_alloc(M, Hd, BF16, dev)
+        linear_dgrad(g, w2_16, M, out=dh, kind=L.EPI_DGELU_BF16, colscale=gate, aux_in=h_pre)
+        linear_wgrad(g, h, grad_buf(w2), grad_buf(b2), M)
+        dx = torch.empty((B, N, D), dtype=F32, device=dev)
+        linear_dgrad(dh, w1_16, M, out=dx.view(M, D), kind=L.EPI_STORE_F32)
+        linear_wgrad(dh, xb, grad_buf(w1), grad_buf(b1), M)
+        return (dx,) + (None,) * 9
+
+
+class AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, wq, bq, wp, bp_, wq16, wp16, gate, grad_enabled):
+        L.require_device(x)
+        B, N, D = x.shape
+        M, dev, H = B * N, x.device, module.num_heads
+        xb = _to_rows_bf16(x)
+        need = grad_enabled and (x.requires_grad or wq.requires_grad)
+        qkv = rows_alloc(M, 3 * D, BF16, dev, extra=128)
+        linear_fwd(xb, wq16, bq, M, out=qkv)
+        o = rows_alloc(M, D, BF16, dev)
+        lse = torch.empty((B, H, N), dtype=F32, device=dev) if need else None
+        call("devit_attn_fwd", ptr(qkv), ptr(o), ptr(lse), ptr(gate), B, N, H, D // H, (D // H) ** -0.5, stream_ptr())
+        y = torch.empty((B, N, D), dtype=F32, device=dev)
+        linear_fwd(o, wp16, bp_, M, out=y.view(M, D), kind=L.EPI_STORE_F32)
+        module.head_output = o[:M].view(B, N, H, D // H)
+        ctx.s = (xb, qkv, o, lse, gate, wq, bq, wp, bp_, wq16, wp16, (B, N, D, H))
+        return y, qkv
+
+    @staticmethod
+    def backward(ctx, dy, dqkv_in):
+        xb, qkv, o, lse, gate, wq, bq, wp, bp_, wq16, wp16, (B, N, D, H) = ctx.s
+        M, dev = B * N, dy.device
+        g = _to_rows_bf16(dy)
+        do = rows_alloc(M, D, BF16, dev)
+        linear_dgrad(g, wp16, M, out=do)
+        linear_wgrad(g, o, grad_buf(wp), grad_buf(bp_), M)
+        dqkv = rows_alloc(M, 3 * D, BF16, dev)
+        call("devit_attn_bwd", ptr(qkv), ptr(o), ptr(do), ptr(lse), ptr(gate),
+             ptr(dqkv_in.contiguous()) if dqkv_in is not None else None, ptr(dqkv), B, N, H, D // H, (D // H) ** -0.5,
+             stream_ptr())
+        dx = torch.empty((B, N, D), dtype=F32, device=dev)
+        linear_dgrad(dqkv, wq16, M, out=dx.view(M, D), kind=L.EPI_STORE_F32)
+        linear_wgrad(dqkv, xb, grad_buf(wq), grad_buf(bq), M)
+        return (dx,) + (None,) * 9
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+class ClsDistillLossFn(torch.autograd.Function):
+    """utils/losses.py:156-177 with a SoftTargetCrossEntropy base criterion; loss + gradient in one launch."""
+
+    @staticmethod
+    def forward(ctx, logits, logits_kd, teacher_logits, soft_targets, kind, alpha, tau):
+        L.require_device(logits)
+        logits, logits_kd = logits.contiguous().float(), logits_kd.contiguous().float()
+        soft_targets = soft_targets.contiguous().float()
+        tl = teacher_logits.contiguous().float() if teacher_logits is not None else None
+        B, Cn = logits.shape
+        loss3 = torch.empty(3, dtype=F32, device=logits.device)
+        dlo, dlk = torch.empty_like(logits), torch.empty_like(logits_kd)
+        call("devit_cls_distill_loss", ptr(logits), ptr(logits_kd), ptr(tl), ptr(soft_targets), B, Cn,
+             {"none": 0, "soft": 1, "hard": 2}[kind], alpha, tau, ptr(loss3), ptr(dlo), ptr(dlk), stream_ptr())
+        ctx.save_for_backward(dlo, dlk)
+        return loss3[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dlo, dlk = ctx.saved_tensors
+        return dlo * g, dlk * g, None, None, None, None, None
+
+
+class RelationLossFn(torch.autograd.Function):
+    """q/k/v feature-relation losses (utils/losses.py:307-328) on PACKED qkv buffers.
+
+    t_qkv: bf16 [>= B*N + 58 rows, 3*Dt], s_qkv likewise with Ds; component j lives in columns [j*D, (j+1)*D).
+    Returns fp32 [3] = (q, k, v) losses.  Gradient flows to the student buffer only."""
+
+    @staticmethod
+    def forward(ctx, s_qkv, t_qkv, B, N, hd_s, hd_t):
+        L.require_device(s_qkv)
+        dev = s_qkv.device
+        Ds, Dt = s_qkv.shape[1] // 3, t_qkv.shape[1] // 3
+        assert s_qkv.shape[0] >= (B - 1) * N + 256 and t_qkv.shape[0] >= (B - 1) * N + 256, "packed qkv needs pad rows"
+        losses = torch.empty(3, dtype=F32, device=dev)
+        grams, stats = [], []
+        for j in range(3):
+            gt = torch.empty((B, 256, 256), dtype=F32, device=dev)
+            gs = torch.empty((B, 256, 256), dtype=F32, device=dev)
+            for buf, Dm, out in ((t_qkv, Dt, gt), (s_qkv, Ds, gs)):
+                f = buf[:, j * Dm:]
+                gemm(f, 3 * Dm, 0, f, 3 * Dm, 0, 256, 256, Dm, kind=L.EPI_STORE_F32, out=out, ldc=256, batch=B,
+                     a_bs=N * 3 * Dm, b_bs=N * 3 * Dm, out_bs=256 * 256)
+            lse_t = torch.empty((B, N), dtype=F32, device=dev)
+            lse_s = torch.empty((B, N), dtype=F32, device=dev)
+            row_kl = torch.empty((B, N), dtype=F32, device=dev)
+            call("devit_relation_stats", ptr(gt), ptr(gs), B, N, 256, hd_t, hd_s, ptr(lse_t), ptr(lse_s), ptr(row_kl),
+                 ptr(losses[j:]), stream_ptr())
+            grams.append((gt, gs))
+            stats.append((lse_t, lse_s))
+        ctx.grams, ctx.stats, ctx.s_qkv = grams, stats, s_qkv
+        ctx.meta = (B, N, hd_s, hd_t, Ds)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, hd_s, hd_t, Ds = ctx.meta
+        s_qkv = ctx.s_qkv
+        dev = s_qkv.device
+        g = g.contiguous().float()
+        d = torch.zeros_like(s_qkv)
+        S = torch.empty((B, 256, 256), dtype=BF16, device=dev)
+        for j in range(3):
+            gt, gs = ctx.grams[j]
+            lse_t, lse_s = ctx.stats[j]
+            call("devit_relation_grad", ptr(gt), ptr(gs), ptr(lse_t), ptr(lse_s), ptr(g[j:]), B, N, 256, hd_t, hd_s,
+                 ptr(S), stream_ptr())
+            f = s_qkv[:, j * Ds:]
+            # dF[b] (rows < N) = S[b] @ F[b]   (F read k-major; rows >= N of S are zero)
+            gemm(S, 256, 0, f, 3 * Ds, 1, 256, Ds, 256, kind=L.EPI_STORE_BF16, out=d[:, j * Ds:], ldc=3 * Ds, batch=B,
+                 a_bs=256 * 256, b_bs=N * 3 * Ds, out_bs=N * 3 * Ds, m_valid=N)
+        ctx.grams = ctx.stats = None
+        return d, None, None, None, None, None

@@ -1,0 +1,210 @@
+/* devit_hip.h -- C ABI of libdevit_hip.so: hand-written gfx950 (MI355X) kernels for the
+ * DeViT hot path (ViT block forward/backward + DEKD distillation losses).
+ *
+ * The reference (falcon-xu/DeViT) has no FFI: its boundary is the PyTorch module surface
+ * (SURVEY.md §8b).  Each entry point below names the reference op sequence it replaces
+ * (file:line in the reference tree).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless noted
+ *   - returns 0 on success, a negative DEVIT_ERR_* otherwise; devit_last_error() has the text
+ *   - never allocates/frees device memory, never synchronises, enqueues only on `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream); safe to capture in a hipGraph
+ *   - bf16 tensors are raw uint16 storage; "f32" is IEEE float
+ *   - rows = tokens: M = B * N (N = 198 tokens for distilled 224x224 models)
+ */
+#ifndef DEVIT_HIP_H
+#define DEVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEVIT_ABI_VERSION 1
+
+enum {
+  DEVIT_OK = 0,
+  DEVIT_ERR_SHAPE = -1,   /* dimension not supported by the kernel's tiling */
+  DEVIT_ERR_ARG = -2,     /* null pointer / bad enum / misaligned pointer */
+  DEVIT_ERR_LAUNCH = -3,  /* HIP reported a launch error */
+  DEVIT_ERR_DEVICE = -4   /* not a gfx950 device / no device */
+};
+
+int devit_version(void);
+const char* devit_last_error(void); /* host string, thread-local, valid until next call */
+/* 0 if device `dev` is gfx950; DEVIT_ERR_DEVICE otherwise (product path refuses to run). */
+int devit_check_device(int dev);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = sum_k A(m,k) * B(n,k), bf16 operands, fp32 accumulate (MFMA 16x16x32).
+ * Replaces every nn.Linear on the path: qkv models/de_vit.py:67, proj :82, fc1 :36, fc2 :45,
+ * PatchEmbed conv-as-GEMM :258 and their autograd backward (dgrad / wgrad).
+ *
+ *   Operands are described by devit_operand:
+ *   kmajor = 0: stored [rows][K] (k contiguous), row stride ld elements       (fwd: X[M][K], W[N][K])
+ *   kmajor = 1: stored [K][rows] (row index contiguous), row stride ld         (dgrad: W as B; wgrad: both)
+ *   row_group/row_skip (k-major only): physical row of reduction row r is r + skip * (r / group + 1)
+ *   (0/0 = dense).  Lets the patch-embed wgrad read token rows 2..197 of every image straight from the
+ *   [B,198,D] gradient.
+ *   batch > 1: operand z uses ptr + z * batch_stride (elements); output uses out + z * out_batch_stride.
+ *   Requirements: M % 128 == 0, N % 128 == 0, K % 64 == 0, 16-byte aligned pointers / strides.
+ *   split_k > 1 is only legal with DEVIT_EPI_ATOMIC_F32.  ep->m_valid > 0 stores only rows m < m_valid
+ *   of each batch (padded per-image Grams of the relation loss).
+ * ---------------------------------------------------------------------------------------- */
+typedef enum {
+  DEVIT_EPI_STORE_BF16 = 0, /* out_bf16 = acc + bias                                           */
+  DEVIT_EPI_GELU_BF16 = 1,  /* out_bf16 = gelu(acc + bias) * colscale; aux_bf16 = acc + bias    */
+                            /*   (Mlp.forward de_vit.py:36-43: fc1, exact-erf GELU, neuron gate) */
+  DEVIT_EPI_RESIDUAL_F32 = 2, /* out_f32 = res_f32 + rowscale[m / rows_per_scale] * (acc + bias) */
+                            /*   (Block.forward :114-115 residual + DropPath); aux_bf16 optional  */
+                            /*   copy of (acc + bias) (the 'attention' output, :119)              */
+  DEVIT_EPI_PATCH_F32 = 3,  /* row m=(b,t): out_f32[b*(T+tok)+tok+t] = acc + bias + pos[tok+t]    */
+                            /*   (forward_features :258-264; cls/dist rows written by            */
+                            /*   devit_embed_tokens)                                             */
+  DEVIT_EPI_DGELU_BF16 = 4, /* out_bf16 = acc * colscale * gelu'(aux_in_bf16)  (fc2 dgrad -> dfc1) */
+  DEVIT_EPI_ATOMIC_F32 = 5, /* out_f32 += acc   (atomicAdd; wgrad with split-K)                  */
+  DEVIT_EPI_STORE_F32 = 6   /* out_f32 = acc + bias                                             */
+} devit_epilogue_kind;
+
+typedef struct {
+  int kind;                /* devit_epilogue_kind */
+  void* out;               /* [M][ldc] bf16 or f32 depending on kind */
+  int ldc;
+  const float* bias;       /* [N] or NULL */
+  const float* colscale;   /* [N] gate (GELU / DGELU) or NULL (= 1) */
+  void* aux;               /* GELU: pre-activation out (bf16, ld = ldc) or NULL; RESIDUAL: bf16 copy or NULL */
+  const void* aux_in;      /* DGELU: saved pre-activation [M][ldc] bf16 */
+  const float* res;        /* RESIDUAL: [M][ldc] f32 input stream (may alias out) */
+  const float* rowscale;   /* RESIDUAL: [M / rows_per_scale] per-sample DropPath scale or NULL */
+  int rows_per_scale;      /* RESIDUAL: tokens per sample (198) */
+  const float* pos;        /* PATCH: [tok + T][N] f32 position embedding */
+  int patch_tokens;        /* PATCH: T = 196 */
+  int extra_tokens;        /* PATCH: tok = 2 (cls + dist) or 1 */
+  int exact_gelu;          /* 1 = erff() (parity mode), 0 = 1.5e-7-accurate fast erf */
+  long long out_batch_stride; /* elements between consecutive batch outputs (out, aux, aux_in, res) */
+  int m_valid;             /* > 0: rows m >= m_valid of each batch are not stored */
+} devit_epilogue;
+
+typedef struct {
+  const void* ptr;         /* bf16 */
+  int ld;                  /* elements */
+  int kmajor;
+  int row_group, row_skip;
+  long long batch_stride;  /* elements */
+} devit_operand;
+
+int devit_gemm_bf16(const devit_operand* A, const devit_operand* B, int M, int N, int K, int batch, int split_k,
+                    const devit_epilogue* ep, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the fp32 residual stream.  Replaces nn.LayerNorm(D, eps=1e-6) at
+ * models/de_vit.py:113 (norm1), :115 (norm2), :286 (final norm) and its backward.
+ *   physical input row of logical row r: in_group > 0 ? (r / in_group) * in_stride + r % in_group : r
+ *   (final norm: only the cls/dist rows are consumed, de_vit.py:288 -> in_group = 2, in_stride = 198)
+ *   y_bf16 / y_f32: either may be NULL.  mean / rstd: [rows] saved for backward (may be NULL).
+ *   D % 128 == 0, D <= 1024.
+ * bwd: dx[phys row] = (dres ? dres[phys row] : 0) + LN'(dy[r]); dx_bf16 (optional) = rowscale * dx as the
+ *   bf16 branch gradient consumed by the previous sub-block's dgrad / wgrad GEMMs;
+ *   dgamma / dbeta [D] (accumulate != 0 adds).  workspace >= devit_layernorm_bwd_workspace(rows, D).
+ * ---------------------------------------------------------------------------------------- */
+int devit_layernorm_fwd(const float* x, int rows, int D, int in_group, int in_stride, const float* gamma,
+                        const float* beta, float eps, void* y_bf16, float* y_f32, float* mean, float* rstd,
+                        void* stream);
+size_t devit_layernorm_bwd_workspace(int rows, int D);
+int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows, int D, int in_group, int in_stride,
+                        const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                        void* dx_bf16, const float* rowscale, int rows_per_scale, float* dgamma, float* dbeta,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention core.  Replaces models/de_vit.py:68-79 (unbind q,k,v; q k^T * scale; softmax;
+ * @ v; transpose; head-gate mul_) and its backward.
+ *   qkv  : bf16 [B*N][3*H*hd], feature index j*H*hd + h*hd + e (output of the qkv GEMM, de_vit.py:67)
+ *   out  : bf16 [B*N][H*hd] (post head gate == Attention.head_output, de_vit.py:77-79)
+ *   lse  : f32 [B][H][N] natural-log sum-exp of the scaled scores (NULL when no backward is needed)
+ *   head_gate: f32 [H] or NULL.   head_dim must be 64, N <= 208.
+ * bwd: dqkv (same layout as qkv) from dout; dqkv_add (optional, same layout) is added in.
+ * ---------------------------------------------------------------------------------------- */
+int devit_attn_fwd(const void* qkv, void* out, float* lse, const float* head_gate, int B, int N, int H, int head_dim,
+                   float scale, void* stream);
+int devit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* head_gate,
+                   const void* dqkv_add, void* dqkv, int B, int N, int H, int head_dim, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch embedding helpers (timm PatchEmbed used at models/de_vit.py:166-168,258 and token assembly
+ * :259-264).  im2row: f32 [B,3,224,224] -> bf16 [B*196][768] with k = c*256 + kh*16 + kw; the
+ * projection itself is devit_gemm_bf16 with DEVIT_EPI_PATCH_F32.  embed_tokens writes
+ * x[b, t, :] = (t == 0 ? cls : dist) + pos[t] for the 1-2 extra tokens (dist == NULL: cls only).
+ * embed_bwd: dpos[T][D] = sum_b dx[b]; dcls = dpos[0]; ddist = dpos[1]; dbias = sum_{t>=ntok} dpos[t];
+ *   dx_bf16 (optional) = bf16 copy of dx for the patch-projection wgrad.
+ * ---------------------------------------------------------------------------------------- */
+int devit_im2row_bf16(const float* img, void* rows, int B, int C, int H, int W, int patch, void* stream);
+int devit_embed_tokens(const float* cls, const float* dist, const float* pos, float* x, int B, int T, int D,
+                       void* stream);
+int devit_embed_bwd(const float* dx, int B, int T, int D, int ntok, float* dpos, float* dcls, float* ddist,
+                    float* dbias, void* dx_bf16, int accumulate, void* stream);
+
+/* f32 -> bf16 cast of a flat buffer (weights, once per optimizer step). */
+int devit_cast_bf16(const float* src, void* dst, size_t n, void* stream);
+
+/* dst_bf16[m][d] = bf16(src[m][d] * (rowscale ? rowscale[m / rows_per_scale] : 1)): turns the fp32
+ * residual-stream gradient into the bf16 branch gradient (DropPath scale folded, de_vit.py:114-115). */
+int devit_scale_cast_bf16(const float* src, void* dst, const float* rowscale, int rows_per_scale, int M, int D,
+                          void* stream);
+
+/* Column sums of a bf16 [M][ld] matrix: out[n] (+)= sum_m y[m][n]  (bias gradients of nn.Linear).
+ * row_group/row_skip as in devit_operand.  workspace >= devit_colsum_workspace(M, N). */
+size_t devit_colsum_workspace(int M, int N);
+int devit_colsum_bf16(const void* y, int M, int N, int ld, int row_group, int row_skip, float* out, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Small strided f32 GEMM  C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + bias[n].
+ * Classifier heads (models/de_vit.py:317) and their backward; exact fp32 FMA chain. */
+int devit_sgemm_small(const float* A, long long sam, long long sak, const float* B, long long sbn, long long sbk,
+                      const float* bias, float* C, int ldc, int M, int N, int K, float alpha, int accumulate,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer tail over FLAT fp32 buffers (engine.py:127 NativeScaler -> clip_grad_norm_ -> AdamW.step,
+ * engine.py:131-132 ModelEma.update): sum of squares (global grad norm), then one fused pass
+ *   g *= grad_scale * min(1, max_norm / (||g|| + 1e-6));  AdamW;  ema = ema*d + (1-d)*p;  p_bf16 = bf16(p)
+ * dyn = device float[3] {lr, 1 - beta1^step, 1 - beta2^step} (device-resident so a captured graph can
+ * be replayed while the schedule advances).  gnorm_sq == NULL: no clipping.  n % 4 == 0.
+ * ---------------------------------------------------------------------------------------- */
+size_t devit_sumsq_workspace(void);
+int devit_sumsq_f32(const float* g, size_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int devit_adamw_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16, const float* gnorm_sq,
+                     const float* dyn, size_t n, float beta1, float beta2, float eps, float weight_decay,
+                     float max_norm, float ema_decay, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DEKD logit loss + gradient in one launch.  Replaces DistillLoss.forward (utils/losses.py:156-177)
+ * with a timm SoftTargetCrossEntropy base criterion (distill_sub.py:348) and its backward.
+ *   kind: 0 none, 1 soft (KL, tau), 2 hard (CE vs argmax of teacher logits, ties -> lowest index)
+ *   loss3 = {total, base, distill};  dlogits / dlogits_kd = d total / d logits (upstream grad 1).
+ * ---------------------------------------------------------------------------------------- */
+int devit_cls_distill_loss(const float* logits, const float* logits_kd, const float* teacher_logits,
+                           const float* soft_targets, int B, int C, int kind, float alpha, float tau, float* loss3,
+                           float* dlogits, float* dlogits_kd, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * q/k/v feature-relation loss (utils/losses.py:307-328).  The per-image Grams F F^T run on
+ * devit_gemm_bf16 (batched, padded to 256x256, DEVIT_EPI_STORE_F32); these two kernels do the rest:
+ * stats: row log-sum-exp of gram / sqrt(head_dim) for teacher and student, per-row KL, and
+ *        loss = sum_{b,i,j} e^{t}(t - s) / B   (KLDivLoss batchmean, log_target)
+ * grad : S = G + G^T, G = (softmax_s - softmax_t) * upstream / (B sqrt(hd_s)), bf16 [B][256][256],
+ *        zero outside N x N; then dF_student = S F_student on devit_gemm_bf16.
+ * ---------------------------------------------------------------------------------------- */
+int devit_relation_stats(const float* gram_t, const float* gram_s, int B, int N, int ldr, int head_dim_t,
+                         int head_dim_s, float* lse_t, float* lse_s, float* row_kl, float* loss, void* stream);
+int devit_relation_grad(const float* gram_t, const float* gram_s, const float* lse_t, const float* lse_s,
+                        const float* upstream, int B, int N, int ldr, int head_dim_t, int head_dim_s, void* S_bf16,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEVIT_HIP_H */

@@ -1,0 +1,338 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against a plain PyTorch fp32 statement of
+the same op on the same (bf16-rounded) inputs.  Tolerances are stated per test: the kernels accumulate in
+fp32, so differences are summation-order noise plus one bf16 rounding of the stored output."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from devit_amd import _lib
+    _lib.require_device(torch.zeros(1, device="cuda"))
+    return torch.device("cuda")
+
+
+def rnd(shape, dev, std=1.0, seed=0, dtype=F32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * std).to(dev).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def bf16_ulp_ok(a, ref, extra=0.0):
+    """stored-bf16 outputs: within 1 bf16 ulp (2^-8 relative) of the fp32 reference + summation noise."""
+    a, ref = a.float(), ref.float()
+    tol = ref.abs() * 2 ** -7 + ref.abs().max() * (1e-5 + extra)
+    bad = (a - ref).abs() > tol
+    assert not bool(bad.any()), f"{int(bad.sum())} elements off; max abs err {float((a - ref).abs().max()):.3e}"
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 256, 192), (1024, 384, 384), (512, 1536, 384)])
+def test_gemm_nt_store(dev, M, N, K):
+    from devit_amd import ops, _lib as L
+    a, w, bias = rnd((M, K), dev, dtype=BF16), rnd((N, K), dev, 0.05, 1, BF16), rnd((N,), dev, 0.1, 2)
+    ref = a.float() @ w.float().t() + bias
+    out = torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=L.EPI_STORE_BF16, out=out, ldc=N, bias=bias)
+    bf16_ulp_ok(out, ref)
+    out32 = torch.empty((M, N), dtype=F32, device=dev)
+    ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=L.EPI_STORE_F32, out=out32, ldc=N, bias=bias)
+    assert relerr(out32, ref) < 2e-5
+
+
+def test_gemm_layout_asymmetric(dev):
+    """A = I-like selector with an asymmetric B catches swapped row/col maps (cdna guide §3)."""
+    from devit_amd import ops, _lib as L
+    M = N = 128
+    K = 128
+    a = torch.zeros((M, K), dtype=BF16, device=dev)
+    a[torch.arange(M), torch.arange(M) % K] = 1
+    w = (torch.arange(N, device=dev)[:, None] * 3 + torch.arange(K, device=dev)[None, :] % 7).to(BF16)
+    out = torch.empty((M, N), dtype=F32, device=dev)
+    ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=L.EPI_STORE_F32, out=out, ldc=N)
+    assert torch.equal(out, a.float() @ w.float().t())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (640, 384, 1536), (384, 1536, 384)])
+def test_gemm_dgrad_kmajor_b(dev, M, N, K):
+    """out[M, N] = dy[M, K] @ W[K, N]  with W read k-major (transposed LDS reads)."""
+    from devit_amd import ops, _lib as L
+    dy, w = rnd((M, K), dev, dtype=BF16), rnd((K, N), dev, 0.05, 1, BF16)
+    out = torch.empty((M, N), dtype=F32, device=dev)
+    ops.gemm(dy, K, 0, w, N, 1, M, N, K, kind=L.EPI_STORE_F32, out=out, ldc=N)
+    assert relerr(out, dy.float() @ w.float()) < 2e-5
+
+
+def test_gemm_kmajor_exact_integers(dev):
+    from devit_amd import ops, _lib as L
+    M, N, K = 128, 256, 192
+    a = ((torch.arange(K, device=dev)[:, None] * 5 + torch.arange(M, device=dev)[None, :]) % 11 - 5).to(BF16)  # [K][M]
+    b = ((torch.arange(K, device=dev)[:, None] * 3 + torch.arange(N, device=dev)[None, :] * 7) % 13 - 6).to(BF16)  # [K][N]
+    out = torch.zeros((M, N), dtype=F32, device=dev)
+    ops.gemm(a, M, 1, b, N, 1, M, N, K, kind=L.EPI_ATOMIC_F32, out=out, ldc=N, split_k=3)
+    assert torch.equal(out, a.float().t() @ b.float())
+
+
+@pytest.mark.parametrize("rows,N,K,split", [(1024, 384, 384, 4), (3200, 1152, 384, 7), (1584 + 80, 128, 256, 1)])
+def test_gemm_wgrad_splitk_atomic(dev, rows, N, K, split):
+    """dW[N, K] += dy[rows, N]^T @ x[rows, K]: both operands k-major, split-K with fp32 atomics."""
+    from devit_amd import ops, _lib as L
+    rows = rows // 64 * 64
+    dy, x = rnd((rows, N), dev, dtype=BF16), rnd((rows, K), dev, seed=3, dtype=BF16)
+    base = rnd((N, K), dev, seed=5)
+    out = base.clone()
+    ops.gemm(dy, N, 1, x, K, 1, N, K, rows, kind=L.EPI_ATOMIC_F32, out=out, ldc=K, split_k=split)
+    ref = base + dy.float().t() @ x.float()
+    assert relerr(out, ref) < 2e-5
+
+
+def test_gemm_epilogues(dev):
+    from devit_amd import ops, _lib as L
+    B, T, D, Hd = 4, 96, 128, 512
+    M = B * T
+    x, w1, b1 = rnd((M, D), dev, dtype=BF16), rnd((Hd, D), dev, 0.08, 1, BF16), rnd((Hd,), dev, 0.1, 2)
+    gate = (rnd((Hd,), dev, seed=4) > -0.5).float()
+    pre_ref = x.float() @ w1.float().t() + b1
+    h = torch.empty((M, Hd), dtype=BF16, device=dev)
+    pre = torch.empty((M, Hd), dtype=BF16, device=dev)
+    ops.gemm(x, D, 0, w1, D, 0, M, Hd, D, kind=L.EPI_GELU_BF16, out=h, ldc=Hd, bias=b1, colscale=gate, aux=pre)
+    bf16_ulp_ok(pre, pre_ref)
+    bf16_ulp_ok(h, torch.nn.functional.gelu(pre_ref) * gate, extra=1e-4)
+    h2 = torch.empty_like(h)
+    ops.gemm(x, D, 0, w1, D, 0, M, Hd, D, kind=L.EPI_GELU_BF16, out=h2, ldc=Hd, bias=b1, exact_gelu=1)
+    bf16_ulp_ok(h2, torch.nn.functional.gelu(pre_ref))
+    # residual + per-sample rowscale
+    w2, b2 = rnd((D, Hd), dev, 0.05, 6, BF16), rnd((D,), dev, 0.1, 7)
+    res, rs = rnd((M, D), dev, seed=8), torch.tensor([0.0, 1.25, 1.0, 1.25], device=dev)
+    out = torch.empty((M, D), dtype=F32, device=dev)
+    att = torch.empty((M, D), dtype=BF16, device=dev)
+    ops.gemm(h, Hd, 0, w2, Hd, 0, M, D, Hd, kind=L.EPI_RESIDUAL_F32, out=out, ldc=D, bias=b2, res=res, rowscale=rs,
+             rows_per_scale=T, aux=att)
+    br = h.float() @ w2.float().t() + b2
+    assert relerr(out, res + rs.repeat_interleave(T)[:, None] * br) < 2e-5
+    bf16_ulp_ok(att, br)
+    # dgelu: out = acc * gate * gelu'(pre)
+    dyv = rnd((M, D), dev, seed=9, dtype=BF16)
+    dh = torch.empty((M, Hd), dtype=BF16, device=dev)
+    ops.gemm(dyv, D, 0, w2, Hd, 1, M, Hd, D, kind=L.EPI_DGELU_BF16, out=dh, ldc=Hd, colscale=gate, aux_in=pre)
+    p32 = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(p32).sum().backward()
+    bf16_ulp_ok(dh, (dyv.float() @ w2.float()) * gate * p32.grad, extra=1e-4)
+    # m_valid guard: rows >= m_valid untouched
+    out2 = torch.full((M, D), 7.0, dtype=F32, device=dev)
+    ops.gemm(h, Hd, 0, w2, Hd, 0, M, D, Hd, kind=L.EPI_STORE_F32, out=out2, ldc=D, m_valid=300)
+    assert bool((out2[300:] == 7.0).all()) and relerr(out2[:300], (h.float() @ w2.float().t())[:300]) < 2e-5
+
+
+def test_gemm_batched_and_patch(dev):
+    from devit_amd import ops, _lib as L
+    B, N, D = 3, 198, 128
+    f = torch.zeros((B * N + 256, 3 * D), dtype=BF16, device=dev)
+    f[: B * N] = rnd((B * N, 3 * D), dev, 0.3, dtype=BF16)
+    g = torch.empty((B, 256, 256), dtype=F32, device=dev)
+    fj = f[:, D:]
+    ops.gemm(fj, 3 * D, 0, fj, 3 * D, 0, 256, 256, D, kind=L.EPI_STORE_F32, out=g, ldc=256, batch=B, a_bs=N * 3 * D,
+             b_bs=N * 3 * D, out_bs=65536)
+    for b in range(B):
+        fb = f[b * N: b * N + N, D:2 * D].float()
+        assert relerr(g[b, :N, :N], fb @ fb.t()) < 2e-5
+    # patch epilogue: row (b,t) -> token row b*198 + 2 + t, + bias + pos
+    Bp, Dm = 2, 128
+    rows = torch.zeros((512, 768), dtype=BF16, device=dev)
+    rows[: Bp * 196] = rnd((Bp * 196, 768), dev, dtype=BF16)
+    w, bias, pos = rnd((Dm, 768), dev, 0.03, 1, BF16), rnd((Dm,), dev, 0.1, 2), rnd((198, Dm), dev, 0.1, 3)
+    x = torch.zeros((Bp, 198, Dm), dtype=F32, device=dev)
+    ops.gemm(rows, 768, 0, w, 768, 0, 512, Dm, 768, kind=L.EPI_PATCH_F32, out=x, ldc=Dm, bias=bias, pos=pos,
+             patch_tokens=196, extra_tokens=2, m_valid=Bp * 196)
+    ref = (rows[: Bp * 196].float() @ w.float().t() + bias).view(Bp, 196, Dm) + pos[2:]
+    assert relerr(x[:, 2:], ref) < 2e-5 and bool((x[:, :2] == 0).all())
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("D", [384, 768])
+def test_layernorm(dev, D):
+    from devit_amd import ops
+    M = 1000
+    x = rnd((M, D), dev, 2.0) + 0.5
+    gm, bt = rnd((D,), dev, 0.1, 1) + 1, rnd((D,), dev, 0.1, 2)
+    y = torch.empty((M, D), dtype=BF16, device=dev)
+    y32 = torch.empty((M, D), dtype=F32, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, M, D, gm, bt, 1e-6, y_bf16=y, y_f32=y32, mean=mean, rstd=rstd)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    assert relerr(y32, ref) < 1e-5
+    bf16_ulp_ok(y, ref)
+    dy = rnd((M, D), dev, seed=4, dtype=BF16)
+    dres = rnd((M, D), dev, seed=5)
+    ref.backward(dy.float())
+    dx = torch.empty((M, D), dtype=F32, device=dev)
+    dxb = torch.empty((M, D), dtype=BF16, device=dev)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    rsc = torch.tensor([0.5, 2.0, 1.0, 0.0], device=dev)
+    ops.layernorm_bwd(dy, False, x, M, D, mean, rstd, gm, dres, dx, dxb, rsc, 250, dg, db)
+    assert relerr(dx, xr.grad + dres) < 1e-5
+    bf16_ulp_ok(dxb, (xr.grad + dres) * rsc.repeat_interleave(250)[:, None])
+    assert relerr(dg, gr.grad) < 1e-4 and relerr(db, br.grad) < 1e-4
+    # row-subset mode (final norm on cls/dist rows only)
+    B, T = 5, 198
+    xs = rnd((B * T, D), dev, seed=7)
+    tok = torch.empty((B * 2, D), dtype=F32, device=dev)
+    ops.layernorm_fwd(xs, B * 2, D, gm, bt, 1e-6, y_f32=tok, in_group=2, in_stride=T)
+    ref2 = torch.nn.functional.layer_norm(xs.view(B, T, D)[:, :2], (D,), gm, bt, 1e-6)
+    assert relerr(tok.view(B, 2, D), ref2) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, B, N, H, gate):
+    D = H * 64
+    v = qkv[: B * N].float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, vv = v[0], v[1], v[2]
+    a = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    o = (a @ vv).transpose(1, 2)
+    if gate is not None:
+        o = o * gate.view(1, 1, H, 1)
+    return o.reshape(B * N, D), a
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 198, 6), (3, 197, 2), (1, 64, 1)])
+def test_attention_fwd_bwd(dev, B, N, H):
+    from devit_amd import ops
+    from devit_amd._lib import call, ptr, stream_ptr
+    D, M = H * 64, B * N
+    qkv = ops.rows_alloc(M, 3 * D, BF16, dev, extra=128)
+    qkv[:M] = rnd((M, 3 * D), dev, 1.0, dtype=BF16)
+    gate = torch.ones(H, device=dev)
+    if H > 1:
+        gate[1] = 0.0
+    out = ops.rows_alloc(M, D, BF16, dev)
+    lse = torch.empty((B, H, N), dtype=F32, device=dev)
+    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, stream_ptr())
+    q32 = qkv[:M].float().requires_grad_(True)
+    ref, _ = attn_ref(q32, B, N, H, gate)
+    bf16_ulp_ok(out[:M], ref, extra=2e-3)      # P is rounded to bf16 before P V
+    vv = q32.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (vv[0] @ vv[1].transpose(-2, -1)) * 0.125
+    assert relerr(lse, torch.logsumexp(s, -1)) < 1e-5
+    assert bool((out[M:] == 0).all())
+    dout = ops.rows_alloc(M, D, BF16, dev)
+    dout[:M] = rnd((M, D), dev, seed=3, dtype=BF16)
+    ref.backward(dout[:M].float())
+    dqkv = ops.rows_alloc(M, 3 * D, BF16, dev)
+    call("devit_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(gate), None, ptr(dqkv), B, N, H, 64, 0.125,
+         stream_ptr())
+    err = relerr(dqkv[:M], q32.grad)
+    assert err < 2e-2, f"dqkv rel-to-max err {err:.3e}"    # bf16 P / dS operands: ~2^-8 relative
+
+
+# ------------------------------------------------------------------------------------------ elementwise
+def test_im2row_embed_cast_colsum(dev):
+    from devit_amd import ops
+    from devit_amd._lib import call, ptr, stream_ptr
+    B = 3
+    img = rnd((B, 3, 224, 224), dev)
+    rows = ops.rows_alloc(B * 196, 768, BF16, dev)
+    call("devit_im2row_bf16", ptr(img), ptr(rows), B, 3, 224, 224, 16, stream_ptr())
+    ref = img.reshape(B, 3, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(B * 196, 768).to(BF16)
+    assert torch.equal(rows[: B * 196], ref)
+    y = rnd((1000, 384), dev, dtype=BF16)
+    out = torch.ones(384, device=dev)
+    ops.colsum(y, 1000, 384, out, accumulate=True)
+    assert relerr(out, 1 + y.float().sum(0)) < 1e-5
+    src = rnd((1001,), dev)
+    src16 = torch.empty(1008, dtype=F32, device=dev)[:1001].copy_(src)
+    assert torch.equal(ops.cast_bf16(src16), src.to(BF16))
+
+
+def test_sgemm_small_and_cls_loss(dev):
+    from devit_amd import ops
+    B, C, D = 16, 25, 384
+    tok, w, b = rnd((B, 2, D), dev), rnd((C, D), dev, 0.05, 1), rnd((C,), dev, 0.1, 2)
+    lo = torch.empty((B, C), device=dev)
+    ops.sgemm_small(tok[:, 1], 2 * D, 1, w, D, 1, b, lo, C, B, C, D)
+    assert relerr(lo, tok[:, 1] @ w.t() + b) < 1e-5
+    lo_, lk_, lt = rnd((B, C), dev, 1.5, 3), rnd((B, C), dev, 1.5, 4), rnd((B, C), dev, 2.0, 5)
+    y = torch.softmax(rnd((B, C), dev, 2.0, 6), -1)
+    for kind, tau in (("hard", 1.0), ("soft", 3.0), ("none", 1.0)):
+        a, k = lo_.clone().requires_grad_(True), lk_.clone().requires_grad_(True)
+        base = torch.sum(-y * torch.log_softmax(a, -1), -1).mean()
+        if kind == "hard":
+            ref = 0.5 * base + 0.5 * torch.nn.functional.cross_entropy(k, lt.argmax(1))
+        elif kind == "soft":
+            la, lb = torch.log_softmax(k / tau, 1), torch.log_softmax(lt / tau, 1)
+            ref = 0.5 * base + 0.5 * torch.sum(lb.exp() * (lb - la)) * tau * tau / k.numel()
+        else:
+            ref = base
+        ref.backward()
+        a2, k2 = lo_.clone().requires_grad_(True), lk_.clone().requires_grad_(True)
+        l = ops.ClsDistillLossFn.apply(a2, k2, lt, y, kind, 0.5, tau)
+        (l * 2.0).backward()
+        assert abs(float(l) - float(ref)) < 1e-5 * max(1, abs(float(ref)))
+        assert relerr(a2.grad, 2 * a.grad) < 1e-5
+        if kind != "none":
+            assert relerr(k2.grad, 2 * k.grad) < 1e-5
+
+
+def test_relation_loss(dev):
+    from devit_amd import ops
+    B, N, Hs, Ht = 3, 198, 2, 4
+    Ds, Dt = Hs * 64, Ht * 64
+    M = B * N
+    s_buf = ops.rows_alloc(M, 3 * Ds, BF16, dev, extra=128)
+    t_buf = ops.rows_alloc(M, 3 * Dt, BF16, dev, extra=128)
+    s_buf[:M] = rnd((M, 3 * Ds), dev, 0.25, 1, BF16)
+    t_buf[:M] = rnd((M, 3 * Dt), dev, 0.25, 2, BF16)
+    s_buf.requires_grad_(True)
+    losses = ops.RelationLossFn.apply(s_buf, t_buf, B, N, 64, 64)
+    wts = torch.tensor([0.2, 0.1, 0.3], device=dev) / 12
+    (losses * wts).sum().backward()
+    s32 = s_buf.detach()[:M].float().requires_grad_(True)
+    ref = []
+    for j in range(3):
+        fs, ft = s32[:, j * Ds:(j + 1) * Ds].view(B, N, Ds), t_buf[:M, j * Dt:(j + 1) * Dt].float().view(B, N, Dt)
+        t = torch.log_softmax(ft @ ft.transpose(1, 2) / 8, -1)
+        s = torch.log_softmax(fs @ fs.transpose(1, 2) / 8, -1)
+        ref.append(torch.sum(t.exp() * (t - s)) / B)
+    ref = torch.stack(ref)
+    (ref * wts).sum().backward()
+    assert relerr(losses, ref) < 1e-4, (losses, ref)
+    err = relerr(s_buf.grad[:M], s32.grad)
+    assert err < 2e-2, f"relation grad rel-to-max err {err:.3e}"
+
+
+def test_adamw_and_sumsq(dev):
+    from devit_amd._lib import call, ptr, stream_ptr, load
+    n = 4096 * 3 + 4
+    p, g = rnd((n,), dev), rnd((n,), dev, 0.3, 1)
+    m, v, ema = torch.zeros(n, device=dev), torch.zeros(n, device=dev), p.clone()
+    p16 = torch.empty(n, dtype=BF16, device=dev)
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    ws = torch.empty(load().devit_sumsq_workspace(), dtype=torch.uint8, device=dev)
+    gsq = torch.empty(1, device=dev)
+    ema_ref = p.clone()
+    for step in (1, 2, 3):
+        ref_p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        ema_ref = ema_ref * 0.999 + 0.001 * ref_p.detach()
+        call("devit_sumsq_f32", ptr(g), n, ptr(gsq), ptr(ws), ws.numel(), stream_ptr())
+        dyn = torch.tensor([1e-3, 1 - 0.9 ** step, 1 - 0.999 ** step], device=dev)
+        call("devit_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), ptr(p16), ptr(gsq), ptr(dyn), n, 0.9, 0.999,
+             1e-8, 0.05, 1.0, 0.999, 1.0, stream_ptr())
+    assert abs(float(gsq) - float((g * g).sum())) < 1e-4 * float((g * g).sum())
+    assert relerr(p, ref_p.detach()) < 1e-5 and relerr(ema, ema_ref) < 1e-5
+    assert torch.equal(p16, p.to(BF16))

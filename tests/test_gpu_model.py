@@ -1,0 +1,190 @@
+"""Model / loss / step parity on a real MI355X against (a) the golden vectors captured from the reference's
+own modules (tests/golden/*.npz) and (b) the CPU oracle on fresh seeded inputs.
+
+Tolerances.  The HIP path computes in bf16 (MFMA operands and stored branch activations; fp32 accumulate,
+fp32 residual stream, fp32 LN / softmax / loss statistics).  The reference's own modules run under
+torch.autocast(bfloat16) differ from their fp32 run by 1.2e-2 of max|logit| (tests/golden/model_*_bf16.npz,
+SURVEY fact 8), so bf16-mode bars are: logits within 3e-2 of max|logit|, top-1 indices bit-exact on the
+fixture set, losses within 2e-2 relative, gradients within 6e-2 of their max.  (BASELINE.json's 1e-3 bar
+is met only by an fp32-input MFMA mode, which is not built yet: DESIGN.md §7.)"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import devit_oracle as O
+from oracle.detgen import det_array
+
+pytestmark = pytest.mark.gpu
+C = 25
+GS, GT = O.GEOMETRY["dedeit"], O.GEOMETRY["deit_base_distilled_patch16_224"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    import devit_amd
+    st_s, st_t = O.make_state(GS, C, "S"), O.make_state(GT, C, "T")
+    s = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None)
+    t = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C)
+    s.load_state_dict(st_s)
+    t.load_state_dict(st_t)
+    return s.to(dev), t.to(dev).eval(), st_s, st_t
+
+
+def rel(a, b):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("which", ["dedeit", "deitb"])
+def test_model_forward_vs_golden(golden, models, dev, which):
+    s, t, _, _ = models
+    m = s if which == "dedeit" else t
+    g = golden(f"model_{which}")
+    img = torch.from_numpy(det_array("img8", (8, 3, 224, 224))).to(dev)
+    m.eval()
+    with torch.no_grad():
+        logits = m(img)
+        d = m(img, distill_token=True, output_qkv=True, output_att=True, output_emb=True, output_encoders=True)
+    assert isinstance(logits, torch.Tensor) and logits.shape == (8, C)
+    e = rel(logits, g["logits"])
+    assert e < 3e-2, f"logits rel-to-max err {e:.3e}"
+    assert np.array_equal(logits.argmax(1).cpu().numpy(), g["top1"])            # top-1 bit-exact
+    assert set(d) == {"output", "qkv", "attention", "encoder", "last_tokens"}
+    assert len(d["qkv"]) == 12 and len(d["attention"]) == 12 and len(d["encoder"]) == 13
+    q, k, v = d["qkv"][5]
+    D = m.embed_dim
+    assert q.shape == (8, D // 64, 198, 64) and q.stride() == (198 * 3 * D, 64, 3 * D, 1)
+    assert rel(q[:2, :, :24], g["q5"]) < 3e-2 and rel(k[:2, :, :24], g["k5"]) < 3e-2 and rel(v[:2, :, :24], g["v5"]) < 3e-2
+    assert rel(d["attention"][5][:2, :24], g["att5"]) < 3e-2
+    assert rel(d["encoder"][-1][:2, :24], g["enc_last"]) < 3e-2
+    assert rel(d["last_tokens"][0], g["last_cls"]) < 3e-2 and rel(d["last_tokens"][1], g["last_dist"]) < 3e-2
+    es = np.stack([[x.mean().item(), x.abs().mean().item()] for x in d["encoder"]])
+    assert np.abs(es - g["enc_stats"]).max() < 2e-2 * np.abs(g["enc_stats"]).max()
+    m.train()
+    with torch.no_grad():
+        tr = m(img)
+    assert isinstance(tr, tuple) and rel(tr[0], g["train_cls"]) < 3e-2 and rel(tr[1], g["train_dist"]) < 3e-2
+    m.eval() if which == "deitb" else None
+
+
+def test_modules_vs_golden(golden, models, dev):
+    s, t, _, _ = models
+    for tag, m, D, H in (("S", s, 384, 6), ("T", t, 768, 12)):
+        g = golden(f"module_{tag}")
+        blk = m.blocks[5]
+        blk.eval()
+        x = torch.from_numpy(det_array(f"x/{tag}", (2, 198, D))).to(dev).requires_grad_(True)
+        sub = lambda z: z[:, ::9]
+        for p in blk.parameters():
+            p.grad = None
+        y = blk.mlp(x)
+        assert rel(sub(y), g["mlp_y"]) < 2e-2
+        y.square().sum().backward()
+        assert rel(sub(x.grad), g["mlp_dx"]) < 4e-2
+        assert rel(blk.mlp.fc1.weight.grad[:8], g["mlp_dw1_rows"]) < 4e-2
+        blk.mlp.gate = torch.from_numpy(g["neuron_gate"])
+        with torch.no_grad():
+            y2 = blk.mlp(x)
+        assert rel(sub(y2), g["mlp_y_gated"]) < 2e-2
+        assert rel(blk.mlp.neuron_output.float().sum(dim=(0, 1)), g["mlp_neuron_output_sum"]) < 2e-2   # post-mask (Q3)
+        blk.mlp.gate = torch.ones(4 * D)
+        x.grad = None
+        a = blk.attn(x, True)
+        assert rel(sub(a["output"]), g["attn_y"]) < 2e-2
+        assert rel(a["qkv"][0][:, :, :16], g["attn_q"]) < 2e-2 and rel(a["qkv"][2][:, :, :16], g["attn_v"]) < 2e-2
+        a["output"].square().sum().backward()
+        assert rel(sub(x.grad), g["attn_dx"]) < 4e-2
+        blk.attn.gate = torch.from_numpy(g["head_gate"])
+        with torch.no_grad():
+            a2 = blk.attn(x, True)
+        assert rel(sub(a2["output"]), g["attn_y_gated"]) < 2e-2
+        assert rel(blk.attn.head_output.float().sum(dim=(0, 1)), g["attn_head_output_sum"]) < 2e-2
+        blk.attn.gate = torch.ones(H)
+        with torch.no_grad():
+            b = blk(x, output_qkv=True, output_att=True)
+        assert rel(sub(b["output"]), g["block_y"]) < 2e-2 and rel(sub(b["attention"]), g["block_att"]) < 2e-2
+        for p in blk.parameters():
+            p.grad = None
+    s.train()
+
+
+def test_losses_vs_golden(golden, dev):
+    import devit_amd
+    g = golden("loss_cls")
+    lo = torch.from_numpy(det_array("lo", (8, C), std=1.5)).to(dev).requires_grad_(True)
+    lk = torch.from_numpy(det_array("lk", (8, C), std=1.5)).to(dev).requires_grad_(True)
+    lt = torch.from_numpy(det_array("lt", (8, C), std=2.0)).to(dev)
+    soft = torch.from_numpy(g["soft_targets"]).to(dev)
+    for kind, tau in (("hard", 1.0), ("soft", 3.0)):
+        crit = devit_amd.DistillLoss(devit_amd.SoftTargetCrossEntropy(), kind, 0.5, tau)
+        l = crit((lo, lk), lt, soft)
+        d = torch.autograd.grad(l, [lo, lk])
+        assert abs(float(l) - float(g[f"{kind}_loss"])) < 1e-5 * abs(float(g[f"{kind}_loss"]))   # fp32 kernel
+        assert rel(d[0], g[f"{kind}_dlo"]) < 1e-5 and rel(d[1], g[f"{kind}_dlk"]) < 1e-5
+    g = golden("loss_relation")
+    tf = torch.from_numpy(det_array("tf", (2, 198, 3, 12, 64), std=0.25)).to(dev).permute(2, 0, 3, 1, 4)[1]
+    sf = torch.from_numpy(det_array("sf", (2, 198, 3, 6, 64), std=0.25)).to(dev).permute(2, 0, 3, 1, 4)[1]
+    sf = sf.detach().requires_grad_(True)
+    l = devit_amd.feature_relation_loss(tf, sf)
+    d, = torch.autograd.grad(l, [sf])
+    assert abs(float(l) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))        # bf16 features
+    assert rel(d[:, :, ::9], g["dstudent"]) < 4e-2
+
+
+def test_distill_step_vs_golden(golden, models, dev):
+    from devit_amd import engine
+    s, t, _, _ = models
+    g = golden("step_bs8")
+    img = torch.from_numpy(det_array("img8", (8, 3, 224, 224))).to(dev)
+    soft = torch.from_numpy(g["soft_targets"]).to(dev)
+    dps = torch.from_numpy(g["dp_scales"]).to(dev)
+    s.train()
+    for p in s.parameters():
+        p.grad = None
+    out = engine.distill_forward(s, t, img, soft, gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0,
+                                 dp_scales=[(dps[i, 0].contiguous(), dps[i, 1].contiguous()) for i in range(12)])
+    for k in ("loss", "cls_loss", "q_loss", "k_loss", "v_loss"):
+        e = abs(float(out[k]) - float(g[k])) / abs(float(g[k]))
+        assert e < 2e-2, f"{k}: {float(out[k])} vs {float(g[k])}"
+    assert rel(out["teacher_logits"], g["teacher_logits"]) < 3e-2
+    out["loss"].backward()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "step_param_names.json")) as f:
+        names = json.load(f)
+    params = dict(s.named_parameters())
+    gn = np.array([params[n].grad.norm().item() for n in names])
+    bad = np.abs(gn - g["grad_norms"]) > 6e-2 * g["grad_norms"] + 1e-3 * g["grad_norms"].max()
+    assert not bad.any(), [(names[i], gn[i], g["grad_norms"][i]) for i in np.nonzero(bad)[0][:8]]
+    assert rel(params["head.weight"].grad, g["g_head_w"]) < 6e-2
+    assert rel(params["blocks.5.attn.qkv.weight"].grad[::48], g["g_qkv5_w_rows"]) < 6e-2
+    assert rel(params["blocks.0.mlp.fc1.weight"].grad[::64], g["g_fc1_0_rows"]) < 6e-2
+    assert rel(params["blocks.11.mlp.fc2.weight"].grad[::16], g["g_fc2_11_rows"]) < 6e-2
+    assert rel(params["pos_embed"].grad[0, ::8], g["g_pos"]) < 6e-2
+    assert rel(params["cls_token"].grad, g["g_cls"]) < 6e-2
+    assert rel(params["patch_embed.proj.weight"].grad[::16].reshape(-1, 768), g["g_patch_w"]) < 6e-2
+    assert rel(params["norm.weight"].grad, g["g_norm_w"]) < 6e-2
+    for p in s.parameters():
+        p.grad = None
+
+
+def test_fresh_inputs_vs_oracle(models, dev):
+    """Seeded inputs that are NOT in the fixture set, bs 4, student eval forward vs the CPU oracle."""
+    s, _, st_s, _ = models
+    img = torch.from_numpy(det_array("fresh", (4, 3, 224, 224), std=0.7))
+    with torch.no_grad():
+        ref = O.forward(st_s, GS, img, training=False)["output"]
+    s.eval()
+    with torch.no_grad():
+        out = s(img.to(dev))
+    assert rel(out, ref.numpy()) < 3e-2
+    assert torch.equal(out.argmax(1).cpu(), ref.argmax(1))
+    s.train()
