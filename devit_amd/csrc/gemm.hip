@@ -262,7 +262,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   if (ep->kind == DEVIT_EPI_RESIDUAL_F32)
     DEVIT_CHECK(ep->res && (!ep->rowscale || ep->rows_per_scale > 0), DEVIT_ERR_ARG, "RESIDUAL: res / rows_per_scale");
   if (ep->kind == DEVIT_EPI_PATCH_F32)
-    DEVIT_CHECK(ep->pos && ep->patch_tokens > 0 && M % ep->patch_tokens == 0 && batch == 1, DEVIT_ERR_ARG,
+    DEVIT_CHECK(ep->pos && ep->patch_tokens > 0 && (ep->m_valid > 0 ? ep->m_valid : M) % ep->patch_tokens == 0 && batch == 1,
+                DEVIT_ERR_ARG,
                 "PATCH: pos / tokens");
   if (ep->kind == DEVIT_EPI_DGELU_BF16) DEVIT_CHECK(ep->aux_in != nullptr, DEVIT_ERR_ARG, "DGELU: aux_in");
 

@@ -1,0 +1,55 @@
+"""Optimizer tail of the DEKD step on flat buffers: global-norm clip + AdamW + EMA + bf16 weight re-cast in two
+launches (devit_sumsq_f32, devit_adamw_step).  Replaces timm NativeScaler -> clip_grad_norm_ -> AdamW.step and
+ModelEma.update (engine.py:127,131-132; ~600 tiny kernels in the reference)."""
+import torch
+
+from . import _lib as L
+from ._lib import call, ptr, stream_ptr
+
+
+class FlatAdamW:
+    """AdamW over ddp.FlatParams.  `weight_decay` is uniform (distill_sub.py:73 default 0)."""
+
+    def __init__(self, flat, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None, ema_decay=None):
+        self.flat, self.betas, self.eps, self.weight_decay = flat, betas, eps, weight_decay
+        self.max_norm, self.ema_decay = max_norm, ema_decay
+        dev = flat.flat.device
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.ema = flat.flat.clone() if ema_decay is not None else None
+        self.step_count = 0
+        self.param_groups = [{"lr": lr, "params": flat.params}]
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._dyn_host = torch.zeros(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(3)
+        self._dyn = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._ws = torch.empty(4096, dtype=torch.uint8, device=dev)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self):
+        L.require_device(self.flat.flat)
+        self.step_count += 1
+        b1, b2 = self.betas
+        self._dyn_host[0] = self.param_groups[0]["lr"]
+        self._dyn_host[1] = 1.0 - b1 ** self.step_count
+        self._dyn_host[2] = 1.0 - b2 ** self.step_count
+        self._dyn.copy_(self._dyn_host, non_blocking=True)
+        f = self.flat
+        clip = self.max_norm is not None and self.max_norm > 0
+        if clip:
+            call("devit_sumsq_f32", ptr(f.flat_grad), f.numel, ptr(self.gnorm_sq), ptr(self._ws), self._ws.numel(),
+                 stream_ptr())
+        call("devit_adamw_step", ptr(f.flat), ptr(f.flat_grad), ptr(self.m), ptr(self.v), ptr(self.ema), None,
+             ptr(self.gnorm_sq) if clip else None, ptr(self._dyn), f.numel, b1, b2, self.eps, self.weight_decay,
+             float(self.max_norm or 0.0), float(self.ema_decay or 0.0), 1.0, stream_ptr())
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "ema": self.ema, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        if self.ema is not None and sd.get("ema") is not None:
+            self.ema.copy_(sd["ema"])
+        self.step_count = sd["step"]
+        self.param_groups[0]["lr"] = sd["lr"]

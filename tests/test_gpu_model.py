@@ -72,8 +72,11 @@ def test_model_forward_vs_golden(golden, models, dev, which):
     assert np.abs(es - g["enc_stats"]).max() < 2e-2 * np.abs(g["enc_stats"]).max()
     m.train()
     with torch.no_grad():
-        tr = m(img)
-    assert isinstance(tr, tuple) and rel(tr[0], g["train_cls"]) < 3e-2 and rel(tr[1], g["train_dist"]) < 3e-2
+        tr = m(img)                     # train mode returns the (cls, dist) tuple, de_vit.py:324-325
+        assert isinstance(tr, tuple) and len(tr) == 2
+        from devit_amd import engine    # golden train outputs were captured with drop_path = 0
+        tr = engine._forward_with_dp(m, img, None)["output"]
+    assert rel(tr[0], g["train_cls"]) < 3e-2 and rel(tr[1], g["train_dist"]) < 3e-2
     m.eval() if which == "deitb" else None
 
 
