@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one distill_sub optimisation step (DeiT-B -> dedeit, bs 256 per GPU,
+224x224, bf16) -- BASELINE.json `metric`.
+
+A step = zero grads, student train forward (output_qkv), teacher eval forward, DEKD losses, backward with the
+bucketed RCCL gradient all-reduce, global-norm clip + AdamW + EMA + bf16 weight re-cast (engine.py:62-132 of
+the reference).  Inputs are synthetic and already resident in HBM; weights are random-init.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (the forward `gemm_kernel<A_row,B_row>`
+template: teacher + student Linear layers); `cpu_baseline` is the CPU oracle (oracle/, "port") timed on this
+box's host cores on a bounded bs-8 sample of the same step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMG_STEP = 63.503      # BASELINE.md §2 (student fwd+bwd 27.740 + teacher fwd 35.311 + relation 0.452)
+BF16_DENSE_PEAK = 2.5e15         # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds):
+    """CPU oracle ("port" of the reference path, pinned to its goldens) on a bounded sample: bs-8 DEKD steps."""
+    from oracle import devit_oracle as O
+    from oracle.detgen import det_array
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gs, gt = O.GEOMETRY["dedeit"], O.GEOMETRY["deit_base_distilled_patch16_224"]
+    st_s = {k: v.requires_grad_(True) for k, v in O.make_state(gs, 25, "S").items()}
+    st_t = O.make_state(gt, 25, "T")
+    img = torch.from_numpy(det_array("cpu_bench", (8, 3, 224, 224)))
+    soft = torch.full((8, 25), 0.1 / 25)
+    soft[:, 3] += 0.9
+    n, t0 = 0, None
+    while True:
+        out = O.distill_step(st_s, gs, st_t, gt, img, soft)
+        out["loss"].backward()
+        for v in st_s.values():
+            v.grad = None
+        if t0 is None:          # first step = warm-up
+            t0 = time.time()
+            continue
+        n += 1
+        if time.time() - t0 > seconds or n >= 20:
+            break
+    dt = time.time() - t0
+    return {"value": round(8 * n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} fp32 DEKD steps (student fwd+bwd, DeiT-B teacher fwd, losses) at bs 8, no optimizer"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import devit_amd
+    from devit_amd import ddp, engine, losses, ops, optim
+
+    B = args.batch_size
+    C = 25 if world == 1 else 250           # BASELINE configs[2] (CIFAR-100/4) at N=1, configs[3] (ImageNet/4) at N>1
+    torch.manual_seed(0)
+    student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None).to(dev).train()
+    torch.manual_seed(1)
+    teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
+    for p in teacher.parameters():
+        p.requires_grad_(False)
+
+    flat = ddp.FlatParams(student).attach_bf16(student)
+    ddp.broadcast_parameters(flat)
+    reducer = ddp.BucketedGradReducer(flat).attach(student)
+    opt = optim.FlatAdamW(flat, lr=5e-4 * B * world / 512.0, weight_decay=0.0, max_norm=1.0, ema_decay=0.99996)
+    criterion = losses.DistillLoss(losses.SoftTargetCrossEntropy(), "hard", 0.5, 1.0)
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    img = torch.randn((B, 3, 224, 224), generator=g, device=dev)
+    y1 = torch.randint(0, C, (B,), generator=g, device=dev)
+    y2 = torch.randint(0, C, (B,), generator=g, device=dev)
+    oh = lambda y: torch.full((B, C), 0.1 / C, device=dev).scatter_(1, y[:, None], 0.9 + 0.1 / C)
+    soft = 0.7 * oh(y1) + 0.3 * oh(y2)       # mixup of two smoothed one-hots
+
+    def step():
+        opt.zero_grad()
+        out = engine.distill_forward(student, teacher, img, soft, gama=(0.2, 0.1, 0.3), criterion=criterion)
+        out["loss"].backward()
+        reducer.finish()
+        opt.step()
+        return out["loss"]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_value = float(loss)
+    assert loss_value == loss_value, "non-finite loss"
+    img_per_s = B * world * args.steps / dt
+
+    # ---- dominant-kernel roofline: one extra instrumented step, events on the launch stream ------------------
+    ops.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    recs, ops.PROFILE = ops.PROFILE, None
+    by_t = {}
+    for tmpl, M, N, K, batch, e0, e1 in recs:
+        d = by_t.setdefault(tmpl, [0.0, 0.0, 0])
+        d[0] += 2.0 * M * N * K * batch
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    dom = "A_row/B_row"
+    fl, tm, cnt = by_t[dom]
+    roof = {"bound": "mfma", "kernel": "gemm_kernel<A_row,B_row> (128x128x64 bf16 MFMA, fwd Linear layers)",
+            "achieved": round(fl / tm / 1e12, 2), "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": round(fl / tm / BF16_DENSE_PEAK, 4), "traffic": None,
+            "launches_per_step": cnt, "avg_launch_us": round(tm / cnt * 1e6, 2),
+            "gflop_per_launch_avg": round(fl / cnt / 1e9, 3),
+            "step_frac": round(img_per_s / world * GFLOP_PER_IMG_STEP * 1e9 / BF16_DENSE_PEAK, 4),
+            "other_templates": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "launches": v[2],
+                                    "ms_per_step": round(v[1] * 1e3, 3)} for k, v in by_t.items() if k != dom},
+            "gemm_ms_per_step": round(sum(v[1] for v in by_t.values()) * 1e3, 3)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec distill_sub step (DeiT-B->dedeit, bs256, 224^2)", "value": round(img_per_s, 2),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"distill_sub step dedeit<-deit_base_distilled_patch16_224, num_division=4 "
+                                   f"(C={C}), bs={B}/GPU, 224x224, hard distillation, drop_path 0.1, AdamW+EMA",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(loss_value, 5)},
+            "roofline": roof, "cpu_baseline": cpu}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,20 @@ class FlatParams:
                 p.data = v
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
         self.index = {id(p): i for i, p in enumerate(ordered)}
+        self.flat16 = None
+
+    def attach_bf16(self, model):
+        """Keep ONE flat bf16 copy of all parameters (rewritten by the fused optimizer kernel every step) and point
+        the GEMM weight caches of the model's Linear / Conv2d children at views of it."""
+        from . import ops
+        self.flat16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
+        ops.cast_bf16(self.flat, self.flat16)
+        for mod in model.modules():
+            w = getattr(mod, "weight", None)
+            if isinstance(mod, (torch.nn.Linear, torch.nn.Conv2d)) and w is not None and id(w) in self.index:
+                o = self.offsets[self.index[id(w)]]
+                mod._w16 = (w._version, self.flat16[o:o + w.numel()].view(w.shape[0], -1), w.data_ptr())
+        return self
 
     def zero_grad(self):
         self.flat_grad.zero_()

@@ -55,6 +55,8 @@ def workspace(device, nbytes):
 def gemm(a, lda, a_km, b, ldb, b_km, M, N, K, *, kind, out, ldc, bias=None, colscale=None, aux=None, aux_in=None,
          res=None, rowscale=None, rows_per_scale=0, pos=None, patch_tokens=0, extra_tokens=0, exact_gelu=0, batch=1,
          a_bs=0, b_bs=0, out_bs=0, m_valid=0, split_k=1, a_group=0, a_skip=0, b_group=0, b_skip=0):
+    if PROFILE is not None:
+        return _profiled_gemm(locals())
     A = L.Operand(a.data_ptr(), lda, a_km, a_group, a_skip, a_bs)
     Bo = L.Operand(b.data_ptr(), ldb, b_km, b_group, b_skip, b_bs)
     ep = L.Epilogue(kind, out.data_ptr(), ldc, _p(bias), _p(colscale), _p(aux), _p(aux_in), _p(res), _p(rowscale),
@@ -64,6 +66,25 @@ def gemm(a, lda, a_km, b, ldb, b_km, M, N, K, *, kind, out, ldc, bias=None, cols
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+# bench.py instrumentation: when PROFILE is a list, every GEMM launch is bracketed by events on the current stream
+# (the stream the kernel is launched on) and recorded as (template, M, N, K, batch, start_event, end_event).
+PROFILE = None
+
+
+def _profiled_gemm(kw):
+    global PROFILE
+    rec, PROFILE = PROFILE, None
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gemm(**kw)
+        e1.record()
+        rec.append((("A_km" if kw["a_km"] else "A_row") + "/" + ("B_km" if kw["b_km"] else "B_row"), kw["M"], kw["N"],
+                    kw["K"], kw["batch"], e0, e1))
+    finally:
+        PROFILE = rec
 
 
 def split_k_for(out_rows, out_cols, ksteps, target_wgs=512):

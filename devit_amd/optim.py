@@ -40,7 +40,7 @@ class FlatAdamW:
         if clip:
             call("devit_sumsq_f32", ptr(f.flat_grad), f.numel, ptr(self.gnorm_sq), ptr(self._ws), self._ws.numel(),
                  stream_ptr())
-        call("devit_adamw_step", ptr(f.flat), ptr(f.flat_grad), ptr(self.m), ptr(self.v), ptr(self.ema), None,
+        call("devit_adamw_step", ptr(f.flat), ptr(f.flat_grad), ptr(self.m), ptr(self.v), ptr(self.ema), ptr(f.flat16),
              ptr(self.gnorm_sq) if clip else None, ptr(self._dyn), f.numel, b1, b2, self.eps, self.weight_decay,
              float(self.max_norm or 0.0), float(self.ema_decay or 0.0), 1.0, stream_ptr())
 
