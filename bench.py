@@ -41,11 +41,24 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Threads the host really gives this process: affinity mask capped by the cgroup CPU quota (a 256-core box may
+    hand the job far fewer; running torch with 256 threads on a quota of a few cores is 100x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(seconds):
     """CPU oracle ("port" of the reference path, pinned to its goldens) on a bounded sample: bs-8 DEKD steps."""
     from oracle import devit_oracle as O
     from oracle.detgen import det_array
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     gs, gt = O.GEOMETRY["dedeit"], O.GEOMETRY["deit_base_distilled_patch16_224"]
     st_s = {k: v.requires_grad_(True) for k, v in O.make_state(gs, 25, "S").items()}

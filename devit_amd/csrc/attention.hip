@@ -40,20 +40,25 @@ __device__ __forceinline__ bf16x8 pbuf_tr_frag(const char* buf, int k0, int c0, 
   return cat8(lds_tr_read(a), lds_tr_read(a + 4 * PSTRIDE * 2));
 }
 
-// Copy rows [0, nrows) of a strided [N][64] bf16 matrix into an LDS image, zero rows >= N.
-__device__ __forceinline__ void load_image(char* img, const __bf16* src, size_t row_stride, int N, int nrows,
-                                           float mul, int tid) {
-  for (int idx = tid; idx < nrows * 8; idx += 256) {
-    const int row = idx >> 3, c = idx & 7;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < N) {
-      v = *(const bf16x8*)(src + (size_t)row * row_stride + c * 8);
-      if (mul != 1.0f) {
+// Copy rows [0, KROWS) of a strided [N][64] bf16 matrix into an LDS image, zero rows >= N.
+// All 7 loads of a thread are issued before the first LDS write (one HBM latency, not seven).
+__device__ __forceinline__ void load_image(char* img, const __bf16* src, size_t row_stride, int N, float mul, int tid) {
+  constexpr int ITERS = KROWS * 8 / 256;
+  bf16x8 v[ITERS];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * mul);
-      }
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * 256, row = idx >> 3, c = idx & 7;
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    v[it] = row < N ? *(const bf16x8*)(src + (size_t)row * row_stride + c * 8) : z;
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * 256, row = idx >> 3, c = idx & 7;
+    if (mul != 1.0f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[it][e] = f2bf(bf2f(v[it][e]) * mul);
     }
-    *(bf16x8*)(img + img_off(row, c)) = v;
+    *(bf16x8*)(img + img_off(row, c)) = v[it];
   }
 }
 
@@ -77,8 +82,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
   const int D = a.H * HD, N = a.N;
   const size_t rs = (size_t)3 * D;
   const __bf16* qbase = a.qkv + (size_t)b * N * rs + h * HD;
-  load_image(k_img, qbase + D, rs, N, KROWS, 1.0f, tid);
-  load_image(v_img, qbase + 2 * D, rs, N, KROWS, 1.0f, tid);
+  load_image(k_img, qbase + D, rs, N, 1.0f, tid);
+  load_image(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
   __syncthreads();
 
   char* pbuf = p_all + wave * (16 * PSTRIDE * 2);
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
   const __bf16* dobase = a.dout + (size_t)b * N * D + h * HD;
   const __bf16* obase = a.out + (size_t)b * N * D + h * HD;
 
-  load_image(q_img, qbase, rs, N, KROWS, 1.0f, tid);
-  load_image(k_img, qbase + D, rs, N, KROWS, 1.0f, tid);
-  load_image(v_img, qbase + 2 * D, rs, N, KROWS, 1.0f, tid);
-  load_image(do_img, dobase, (size_t)D, N, KROWS, gate, tid);
+  load_image(q_img, qbase, rs, N, 1.0f, tid);
+  load_image(k_img, qbase + D, rs, N, 1.0f, tid);
+  load_image(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
+  load_image(do_img, dobase, (size_t)D, N, gate, tid);
   // zero the P / dS buffers once: key columns of tile 13 (208..223) stay zero for the dQ k-steps
   for (int i = tid; i < (2 * 32 * PSTRIDE * 2) / 16; i += 256) ((f32x4*)p_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (tid < KROWS) {

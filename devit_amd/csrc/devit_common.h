@@ -75,6 +75,16 @@ __device__ __forceinline__ float gelu_bwd(float x) {
   return 0.5f * (1.0f + e) + x * pdf;
 }
 
+// ---- streaming global accesses ------------------------------------------------------------------------
+// Measured on MI355X (gemm_bench, T qkv 50688x2304x768): write-through (sc1) 8/16-byte epilogue stores cost
+// -12 % (833 -> 734 TF; narrow sc1 stores are one fabric write each), so outputs use plain stores.
+__device__ __forceinline__ void store16_stream(void* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void store8_stream(void* p, bf16x4 v) { *(bf16x4*)p = v; }
+template <typename T>
+__device__ __forceinline__ T load_stream(const T* p) {   // read-once data: non-temporal hint
+  return __builtin_nontemporal_load(p);
+}
+
 // ---- MFMA 16x16x32 bf16 -------------------------------------------------------------------
 // A frag: lane l holds A[row l&15][k = 8*(l>>4) + j], j = 0..7
 // B frag: lane l holds B[k = 8*(l>>4) + j][col l&15]

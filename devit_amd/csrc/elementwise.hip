@@ -85,11 +85,20 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* y, int M
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial, int nparts, int ncols, float* out,
                                                            int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncols) return;
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * ncols + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < ncols)
+    for (int p = grp; p < nparts; p += 8) s += partial[(size_t)p * ncols + c];
+  red[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // ---- embedding backward: dpos[t][d] = sum_b dx[b][t][d]; bf16 copy of dx for the patch wgrad ------------
@@ -269,7 +278,7 @@ extern "C" int devit_colsum_bf16(const void* y, int M, int N, int ld, int row_gr
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 255) / 256, nchunk), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)y, M, N, ld, row_group, row_skip, (float*)workspace);
   DEVIT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, nchunk, N, out, accumulate);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;

@@ -11,13 +11,13 @@
 // Both are conflict-free for the MFMA 16x16x32 fragment maps (derivation in DESIGN.md §4.1).
 // The accumulator tile is staged through LDS (reusing the operand buffers) so that every epilogue
 // reads/writes global memory in whole 128/256-byte row segments.
+#include <stdlib.h>
+
 #include "devit_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB, either layout
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int BK = 64;
 
 struct GemmArgs {
   const __bf16* A;
@@ -27,6 +27,7 @@ struct GemmArgs {
   long long a_bs, b_bs;
   int M, N, K;
   int tiles_m, tiles_n, split_k;
+  int gn;  // n-tiles per L2 chunk: tiles are ordered chunk-major, then m, then n inside the chunk
   devit_epilogue ep;
 };
 
@@ -34,53 +35,92 @@ __device__ __forceinline__ int phys_row(int r, int group, int skip) {
   return group > 0 ? r + skip * (r / group + 1) : r;
 }
 
-// Issue the 4 LDS-DMA loads of this wave for one operand tile.
-//   KM == false: operand stored [R][K]; `org` = &op[row0][0], tile = rows row0..+127, k = k0..+63
-//   KM == true : operand stored [K][R]; `org` = &op[0][col0], tile = k rows k0..+63, cols col0..+127
-template <bool KM>
+// Issue this wave's LDS-DMA loads (1 KiB each) for one operand tile of width W (128 or 256).
+//   KM == false: operand stored [R][K]; `org` = &op[row0][0]; LDS image [W rows][64 k] (128-B rows)
+//   KM == true : operand stored [K][R]; `org` = &op[0][col0]; LDS image [64 k][W cols] (2W-B rows)
+template <bool KM, int W, int NWAVES>
 __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, int group, int skip,
                                            char* lds_tile, int wave, int lane) {
+  constexpr int CNT = (W / 8) / NWAVES;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int slab = wave * 4 + i;
+  for (int i = 0; i < CNT; ++i) {
+    const int slab = wave * CNT + i;
     const __bf16* src;
     if (!KM) {
       const int row = slab * 8 + (lane >> 3);
+#ifdef DEVIT_GEMM_NOSWZ
+      const int chunk = (lane & 7);
+#else
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+#endif
       src = org + (size_t)row * ld + k0 + chunk * 8;
     } else {
-      const int krow = slab * 4 + (lane >> 4);
+      constexpr int LPR = W / 8, RPS = 64 / LPR;  // lanes per k-row, k-rows per 1-KiB slab
+      const int krow = slab * RPS + lane / LPR;
       const int h = (krow & 3) | (((krow >> 3) & 1) << 2);
-      const int chunk = (lane & 15) ^ (h << 1);
+      const int chunk = (lane % LPR) ^ (h << 1);
       src = org + (size_t)phys_row(k0 + krow, group, skip) * ld + chunk * 8;
     }
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + slab * 1024), 16, 0, 0);
   }
 }
 
-// One MFMA operand fragment (16 rows/cols starting at t16 of the 128-wide tile, k-step kk of 2).
-template <bool KM>
+// One MFMA operand fragment (16 rows/cols starting at t16 of the W-wide tile, k-step kk of 2).
+template <bool KM, int W>
 __device__ __forceinline__ bf16x8 read_frag(const char* tile, int t16, int kk, int lane) {
   if (!KM) {
     const int row = t16 + (lane & 15);
+#ifdef DEVIT_GEMM_NOSWZ
+    const int chunk = (kk * 4 + (lane >> 4));
+#else
     const int chunk = (kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+#endif
     return *(const bf16x8*)(tile + row * 128 + chunk * 16);
   } else {
     const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int h = q | ((G & 1) << 2);
     const int chunk = ((t16 >> 3) + (p >> 1)) ^ (h << 1);
     const int krow = kk * 32 + G * 8 + q;
-    const char* a = tile + krow * 256 + chunk * 16 + (p & 1) * 8;
-    return cat8(lds_tr_read(a), lds_tr_read(a + 4 * 256));
+    const char* a = tile + krow * (W * 2) + chunk * 16 + (p & 1) * 8;
+    return cat8(lds_tr_read(a), lds_tr_read(a + 4 * (W * 2)));
   }
 }
 
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+#ifdef DEVIT_GEMM_STAMPS
+// Diagnostic build only (tools/build_stamps.sh): per-wave cycle totals of the K-loop segments.
+__device__ unsigned long long devit_gemm_stamps[4];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(v) const unsigned long long v = stamp()
+#else
+#define STAMP(v)
+#endif
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// BM x BN x 64 tile, WAVES_M x WAVES_N waves (each (BM/WAVES_M) x (BN/WAVES_N)), NSTAGE-deep LDS ring filled
+// by LDS-DMA.  One raw barrier per K-step; the DMA of the NSTAGE-2 newest stages stays in flight across it
+// (counted vmcnt), cdna_hip_programming.md "Pipelining across barriers".
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NWAVES = WAVES_M * WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
+  static_assert(WN == 64 && WM % 64 == 0, "wave tile must be (64 k) x 64");
+  constexpr int A_TILE_BYTES = BM * BK * 2, B_TILE_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+  constexpr int PER = (BM / 8 + BN / 8) / NWAVES;  // LDS-DMA instructions per wave per stage
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
   // contiguous run of tiles, n-tile fastest, so one A row-panel is fetched from HBM once per XCD.
@@ -90,9 +130,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
     w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tn = w % g.tiles_n;
-  const int tm = (w / g.tiles_n) % g.tiles_m;
-  const int zz = w / (g.tiles_n * g.tiles_m);
+  const int per_z = g.tiles_n * g.tiles_m;
+  const int zz = w / per_z;
+  int tm, tn;
+  {
+    const int r0 = w - zz * per_z;
+    const int chunk = r0 / (g.gn * g.tiles_m);          // full chunks come first
+    const int r1 = r0 - chunk * g.gn * g.tiles_m;
+    const int width = min(g.gn, g.tiles_n - chunk * g.gn);
+    tm = r1 / width;
+    tn = chunk * g.gn + r1 % width;
+  }
   const int z = zz % g.split_k, bz = zz / g.split_k;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk_total = g.K / BK;
@@ -103,55 +151,83 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   const __bf16* a_org = g.A + (size_t)bz * g.a_bs + (A_KM ? (size_t)m0 : (size_t)m0 * g.lda);
   const __bf16* b_org = g.B + (size_t)bz * g.b_bs + (B_KM ? (size_t)n0 : (size_t)n0 * g.ldb);
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) {
-    stage_tile<A_KM>(a_org, g.lda, kt0 * BK, g.a_group, g.a_skip, smem, wave, lane);
-    stage_tile<B_KM>(b_org, g.ldb, kt0 * BK, g.b_group, g.b_skip, smem + TILE_BYTES, wave, lane);
-  }
-  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
+  auto stage = [&](int t) {
+    char* buf = smem + (t % NSTAGE) * STAGE_BYTES;
+    stage_tile<A_KM, BM, NWAVES>(a_org, g.lda, (kt0 + t) * BK, g.a_group, g.a_skip, buf, wave, lane);
+    stage_tile<B_KM, BN, NWAVES>(b_org, g.ldb, (kt0 + t) * BK, g.b_group, g.b_skip, buf + A_TILE_BYTES, wave, lane);
+  };
 
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s);
+
+#ifdef DEVIT_GEMM_STAMPS
+  unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+#endif
   for (int t = 0; t < nk; ++t) {
-    char* cur = smem + (t & 1) * STAGE_BYTES;
-    if (t + 1 < nk) {
-      char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-      stage_tile<A_KM>(a_org, g.lda, (kt0 + t + 1) * BK, g.a_group, g.a_skip, nxt, wave, lane);
-      stage_tile<B_KM>(b_org, g.ldb, (kt0 + t + 1) * BK, g.b_group, g.b_skip, nxt + TILE_BYTES, wave, lane);
-    }
+    STAMP(s0);
+    // stage t must have landed; the NSTAGE-2 stages issued after it may stay in flight
+    if (t + NSTAGE - 2 < nk) wait_vmcnt<PER * (NSTAGE - 2)>();
+    else wait_vmcnt<0>();
+    STAMP(s1);
+    __builtin_amdgcn_s_barrier();  // everyone's stage-t DMA landed; everyone finished reading stage t-1
+    STAMP(s2);
+    if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1);  // overwrites the buffer read at step t-1
+    STAMP(s3);
+    const char* cur = smem + (t % NSTAGE) * STAGE_BYTES;
+#ifdef DEVIT_GEMM_NOCOMPUTE
+    if (g.K < 0)
+#endif
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[MI], bfr[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = read_frag<A_KM>(cur, wm * 64 + i * 16, kk, lane);
+      for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN>(cur + A_TILE_BYTES, wn * WN + j * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = read_frag<B_KM>(cur + TILE_BYTES, wn * 64 + j * 16, kk, lane);
+      for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM>(cur, wm * WM + i * 16, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
     }
-    __syncthreads();
+#ifdef DEVIT_GEMM_STAMPS
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // let the last MFMAs drain before the stamp
+    STAMP(s4);
+    c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
+#endif
   }
+#ifdef DEVIT_GEMM_STAMPS
+  if (lane == 0) {
+    atomicAdd(&devit_gemm_stamps[0], c_wait); atomicAdd(&devit_gemm_stamps[1], c_bar);
+    atomicAdd(&devit_gemm_stamps[2], c_issue); atomicAdd(&devit_gemm_stamps[3], c_comp);
+  }
+#endif
+  __syncthreads();  // all fragment reads done before the ring is reused as the epilogue staging area
 
-  // ---- epilogue: accumulators -> this wave's private 64x64 f32 LDS tile -> row-wise global I/O
+  // ---- epilogue: accumulators -> this wave's private 64x64 f32 LDS tile -> row-wise global I/O,
+  //      one pass per 64 rows of the wave tile
   float* cw = (float*)smem + wave * 4096;
+  const devit_epilogue& ep = g.ep;
+  const size_t ob = (size_t)bz * ep.out_batch_stride;
+  const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
+  const int nw = n0 + wn * WN;
+#pragma unroll
+  for (int pass = 0; pass < MI / 4; ++pass) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        cw[(i * 16 + (lane >> 4) * 4 + r) * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+        cw[(i * 16 + (lane >> 4) * 4 + r) * 64 + j * 16 + (lane & 15)] = acc[pass * 4 + i][j][r];
   // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
-
-  const devit_epilogue& ep = g.ep;
-  const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-  const size_t ob = (size_t)bz * ep.out_batch_stride;
-  const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
+  const int mw = m0 + wm * WM + pass * 64;
 
   if (ep.kind == DEVIT_EPI_ATOMIC_F32) {
     float* out = (float*)ep.out + ob;
@@ -159,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
       const float v = cw[row * 64 + lane];
       if (mw + row < m_lim) unsafeAtomicAdd(out + (size_t)(mw + row) * ep.ldc + nw + lane, v);
     }
-    return;
+    continue;
   }
 
   const int col = (lane & 15) * 4;
@@ -179,15 +255,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     switch (ep.kind) {
       case DEVIT_EPI_STORE_BF16: {
         bf16x4 ob = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *(bf16x4*)((__bf16*)ep.out + o) = ob;
+        store8_stream((__bf16*)ep.out + o, ob);
       } break;
       case DEVIT_EPI_STORE_F32: {
-        *(f32x4*)((float*)ep.out + o) = v;
+        store16_stream((float*)ep.out + o, v);
       } break;
       case DEVIT_EPI_GELU_BF16: {
         if (ep.aux) {
           bf16x4 pb = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *(bf16x4*)((__bf16*)ep.aux + o) = pb;
+          store8_stream((__bf16*)ep.aux + o, pb);
         }
         f32x4 a;
         if (ep.exact_gelu) {
@@ -198,10 +274,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
           for (int c = 0; c < 4; ++c) a[c] = gelu_fwd<false>(v[c]) * cs[c];
         }
         bf16x4 ob = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
-        *(bf16x4*)((__bf16*)ep.out + o) = ob;
+        store8_stream((__bf16*)ep.out + o, ob);
       } break;
       case DEVIT_EPI_DGELU_BF16: {
-        const bf16x4 pre = *(const bf16x4*)((const __bf16*)ep.aux_in + o);
+        const bf16x4 pre = load_stream((const bf16x4*)((const __bf16*)ep.aux_in + o));
         f32x4 a;
         if (ep.exact_gelu) {
 #pragma unroll
@@ -211,29 +287,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
           for (int c = 0; c < 4; ++c) a[c] = v[c] * cs[c] * gelu_bwd<false>(bf2f(pre[c]));
         }
         bf16x4 ob = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
-        *(bf16x4*)((__bf16*)ep.out + o) = ob;
+        store8_stream((__bf16*)ep.out + o, ob);
       } break;
       case DEVIT_EPI_RESIDUAL_F32: {
         if (ep.aux) {
           bf16x4 pb = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *(bf16x4*)((__bf16*)ep.aux + o) = pb;
+          store8_stream((__bf16*)ep.aux + o, pb);
         }
         const float rs = ep.rowscale ? ep.rowscale[m / ep.rows_per_scale] : 1.0f;
-        const f32x4 r = *(const f32x4*)(ep.res + o);
-        *(f32x4*)((float*)ep.out + o) = r + rs * v;
+        const f32x4 r = load_stream((const f32x4*)(ep.res + o));
+        store16_stream((float*)ep.out + o, r + rs * v);
       } break;
       case DEVIT_EPI_PATCH_F32: {
         const int b = m / ep.patch_tokens, t = m - b * ep.patch_tokens;
         const int tok = ep.extra_tokens + t;
         const f32x4 pe = *(const f32x4*)(ep.pos + (size_t)tok * ep.ldc + n);
         const size_t orow = (size_t)b * (ep.patch_tokens + ep.extra_tokens) + tok;
-        *(f32x4*)((float*)ep.out + orow * ep.ldc + n) = v + pe;
+        store16_stream((float*)ep.out + orow * ep.ldc + n, v + pe);
       } break;
       default:
         break;
     }
   }
+  }  // pass
 }
+
+#ifdef DEVIT_GEMM_STAMPS
+}  // namespace
+extern "C" int devit_debug_gemm_stamps(unsigned long long* out4, int reset) {
+  hipMemcpyFromSymbol(out4, HIP_SYMBOL(devit_gemm_stamps), 32);
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(devit_gemm_stamps), z, 32); }
+  return 0;
+}
+namespace {
+#endif
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -245,8 +332,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   const void* A = Aop->ptr;
   const void* B = Bop->ptr;
   const int lda = Aop->ld, ldb = Bop->ld, a_kmajor = Aop->kmajor, b_kmajor = Bop->kmajor;
-  DEVIT_CHECK(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0 && batch >= 1, DEVIT_ERR_SHAPE,
-              "devit_gemm_bf16: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, BM, BN, BK);
+  DEVIT_CHECK(M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0 && K % BK == 0 && batch >= 1, DEVIT_ERR_SHAPE,
+              "devit_gemm_bf16: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, 128, 128, BK);
   DEVIT_CHECK(lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B) && aligned16(ep->out) &&
                   ep->ldc % 4 == 0 && Aop->batch_stride % 8 == 0 && Bop->batch_stride % 8 == 0 &&
                   ep->out_batch_stride % 4 == 0,
@@ -273,20 +360,56 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   g.a_group = Aop->row_group; g.a_skip = Aop->row_skip; g.b_group = Bop->row_group; g.b_skip = Bop->row_skip;
   g.a_bs = Aop->batch_stride; g.b_bs = Bop->batch_stride;
   g.M = M; g.N = N; g.K = K;
-  g.tiles_m = M / BM; g.tiles_n = N / BN; g.split_k = split_k;
+  g.tiles_m = 0; g.tiles_n = 0; g.split_k = split_k;
+  {
+    // keep one chunk of B (gn * 128 rows x K) around 1 MiB so it stays in the XCD's 4 MiB L2 while A streams
+    static const int gn_env = getenv("DEVIT_GEMM_GN") ? atoi(getenv("DEVIT_GEMM_GN")) : 0;
+    int gn = gn_env > 0 ? gn_env : (int)((1 << 20) / ((long long)128 * K * 2));
+    if (gn < 1) gn = 1;
+    g.gn = gn;
+  }
   g.ep = *ep;
+  // tile choice: 256x256 (8 waves of 128x64, 2-deep ring) when both dims allow, else 256x128 (8 waves of
+  // 64x64, 3-deep ring), else 128x128 (4 waves)
+  static const int force = getenv("DEVIT_GEMM_TILE") ? atoi(getenv("DEVIT_GEMM_TILE")) : 0;  // 1: 128x128, 2: 256x128
+  int cfg = (M % 256 == 0 && N % 256 == 0) ? 3 : (M % 256 == 0 ? 2 : 1);
+  if (force > 0 && force < cfg) cfg = force;
+  const int bm = cfg == 1 ? 128 : 256, bn = cfg == 3 ? 256 : 128;
+  g.tiles_m = M / bm;
+  g.tiles_n = N / bn;
+  if (g.gn > g.tiles_n) g.gn = g.tiles_n;
   const long long nwg = (long long)g.tiles_m * g.tiles_n * split_k * batch;
   DEVIT_CHECK(nwg < (1ll << 31), DEVIT_ERR_SHAPE, "devit_gemm_bf16: grid too large");
-  dim3 grid((unsigned)nwg), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (!a_kmajor && !b_kmajor)
-    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, g);
-  else if (!a_kmajor && b_kmajor)
-    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, g);
-  else if (a_kmajor && b_kmajor)
-    hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, s, g);
-  else
-    hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, s, g);
+  const int variant = (a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0);
+#define DEVIT_LAUNCH_GEMM(BM_, BN_, WMM_, WNN_, NS_)                                                           \
+  do {                                                                                                         \
+    constexpr int ring = NS_ * (BM_ + BN_) * 128, stagebytes = WMM_ * WNN_ * 16384;                            \
+    constexpr int lds = ring > stagebytes ? ring : stagebytes;                                                 \
+    static bool attr[4] = {false, false, false, false};                                                        \
+    const void* fn = variant == 0   ? (const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, false, false>        \
+                     : variant == 1 ? (const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, false, true>         \
+                     : variant == 2 ? (const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, true, false>         \
+                                    : (const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, true, true>;         \
+    if (!attr[variant]) {                                                                                      \
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                 \
+      DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
+      attr[variant] = true;                                                                                    \
+    }                                                                                                          \
+    dim3 grid((unsigned)nwg), block(WMM_* WNN_ * 64);                                                          \
+    if (variant == 0)                                                                                          \
+      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, false, false>), grid, block, lds, s, g);      \
+    else if (variant == 1)                                                                                     \
+      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, false, true>), grid, block, lds, s, g);       \
+    else if (variant == 2)                                                                                     \
+      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, true, false>), grid, block, lds, s, g);       \
+    else                                                                                                       \
+      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, true, true>), grid, block, lds, s, g);        \
+  } while (0)
+  if (cfg == 3) DEVIT_LAUNCH_GEMM(256, 256, 2, 4, 2);
+  else if (cfg == 2) DEVIT_LAUNCH_GEMM(256, 128, 4, 2, 3);
+  else DEVIT_LAUNCH_GEMM(128, 128, 2, 2, 2);
+#undef DEVIT_LAUNCH_GEMM
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }

@@ -156,15 +156,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   }
 }
 
-// out[c] (+)= sum_p partial[p][c]   (deterministic order)
+// out[c] (+)= sum_p partial[p][c]   (deterministic order; 32 columns x 8 part-groups per block)
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* partial, int nparts, int ncols,
                                                               float* out0, float* out1, int D, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncols) return;
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * ncols + c];
-  float* dst = c < D ? out0 + c : out1 + (c - D);
-  *dst = accumulate ? *dst + s : s;
+  if (c < ncols)
+    for (int p = grp; p < nparts; p += 8) s += partial[(size_t)p * ncols + c];
+  red[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][cl];
+    float* dst = c < D ? out0 + c : out1 + (c - D);
+    *dst = accumulate ? *dst + t : t;
+  }
 }
 
 template <typename Args, typename F>
@@ -222,7 +231,7 @@ extern "C" int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x
   });
   DEVIT_CHECK(rc == 0, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: unsupported D=%d", D);
   DEVIT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, grid, 2 * D, dgamma, dbeta, D, accumulate);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;

@@ -21,7 +21,7 @@ from . import _lib as L
 from ._lib import call, ptr, stream_ptr
 
 BF16, F32 = torch.bfloat16, torch.float32
-ROW_TILE = 128
+ROW_TILE = 256
 
 
 def pad_rows(m):

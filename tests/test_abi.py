@@ -1,0 +1,93 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds/loads, exports exactly the symbols that
+include/devit_hip.h declares, the ctypes table matches, and the product path refuses to run without a GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "devit_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(devit_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from devit_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from devit_amd import _lib
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = sorted(set(re.findall(r" T (devit_[a-z0-9_]+)", out)))
+    assert set(decl) <= set(exported), sorted(set(decl) - set(exported))
+    assert set(decl) == set(_lib.SIGNATURES), (sorted(set(decl) ^ set(_lib.SIGNATURES)))
+    for name in decl:
+        assert hasattr(lib, name)
+
+
+def test_version_and_error_string(lib):
+    assert lib.devit_version() == 1
+    assert isinstance(lib.devit_last_error(), bytes)
+
+
+def _struct_fields(name):
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    end = src.index("} %s;" % name)
+    body = src[src.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+    fields = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if stmt:
+            for piece in stmt.split(","):
+                fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", piece)[-1])
+    return fields
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors of devit_epilogue / devit_operand list the same fields in the same order."""
+    from devit_amd import _lib
+    assert _struct_fields("devit_epilogue") == [f[0] for f in _lib.Epilogue._fields_]
+    assert _struct_fields("devit_operand") == [f[0] for f in _lib.Operand._fields_]
+
+
+def test_no_cpu_fallback():
+    """A CPU tensor must raise: there is no PyTorch / oracle fallback on the product path."""
+    import devit_amd
+    from devit_amd._lib import DevitError
+    m = devit_amd.create_model("dedeit", num_classes=25)
+    with pytest.raises(DevitError):
+        m(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(DevitError):
+        devit_amd.feature_relation_loss(torch.zeros(1, 12, 198, 64), torch.zeros(1, 6, 198, 64))
+    with pytest.raises(DevitError):
+        devit_amd.DistillLoss(devit_amd.SoftTargetCrossEntropy(), "hard", 0.5, 1.0)(
+            (torch.zeros(2, 5), torch.zeros(2, 5)), torch.zeros(2, 5), torch.zeros(2, 5))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from devit_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DevitError):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "devit_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f

@@ -1,0 +1,70 @@
+"""world_size-2 gloo test of the data-parallel gradient exchange (devit_amd/ddp.py) on CPU: bucketed, reverse-order
+all-reduce fired from grad_ready callbacks must equal the mean of the per-rank gradients."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from devit_amd import ddp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)                       # same init on every rank
+    model = torch.nn.Sequential(torch.nn.Linear(24, 48), torch.nn.GELU(), torch.nn.Linear(48, 48), torch.nn.Linear(48, 5))
+    if rank == 1:                              # rank 1 starts different: the initial broadcast must fix it
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    flat = ddp.FlatParams(model)
+    ddp.broadcast_parameters(flat)
+    red = ddp.BucketedGradReducer(flat, bucket_bytes=4096)
+    assert len(red.buckets) >= 2
+    torch.manual_seed(100 + rank)              # different data per rank
+    x, y = torch.randn(16, 24), torch.randn(16, 5)
+    ref = torch.nn.Sequential(torch.nn.Linear(24, 48), torch.nn.GELU(), torch.nn.Linear(48, 48), torch.nn.Linear(48, 5))
+    ref.load_state_dict(model.state_dict())
+    (ref(x) - y).square().mean().backward()
+    local = [p.grad.clone() for p in ref.parameters()]
+    # emulate the HIP path: kernels accumulate into param.grad, groups are reported in backward order
+    flat.zero_grad()
+    params = list(model.parameters())
+    for p, g in reversed(list(zip(params, local))):
+        p.grad.add_(g)
+        red.mark_ready([p])
+    red.finish()
+    gathered = [torch.zeros_like(torch.cat([g.reshape(-1) for g in local])) for _ in range(world)]
+    dist.all_gather(gathered, torch.cat([g.reshape(-1) for g in local]))
+    mean = sum(gathered) / world
+    got = torch.cat([p.grad.reshape(-1) for p in params])
+    ok = torch.allclose(got, mean, rtol=1e-6, atol=1e-7)
+    w0 = torch.cat([p.detach().reshape(-1) for p in params])
+    allw = [torch.zeros_like(w0) for _ in range(world)]
+    dist.all_gather(allw, w0)
+    ok = ok and torch.equal(allw[0], allw[1])
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res

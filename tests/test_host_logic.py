@@ -1,0 +1,84 @@
+"""CPU-only tests of the host side that mirrors the reference's module / registry / checkpoint surface."""
+import json
+import os
+
+import pytest
+import torch
+
+import devit_amd
+from devit_amd import de_vit, ddp, ops, registry
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_registry_semantics():
+    assert {"dedeit", "devit", "deit_base_distilled_patch16_224", "deit_tiny_patch16_224",
+            "vit_large_patch16_224"} <= set(registry.list_models())
+    with pytest.raises(RuntimeError):
+        registry.create_model("no_such_model")
+    m = registry.create_model("dedeit", pretrained=False, num_classes=25, resize_dim=None, drop_rate=0.0,
+                              drop_path_rate=0.1, drop_block_rate=None)        # None kwargs dropped (timm)
+    assert m.num_classes == 25 and m.embed_dim == 384 and len(m.blocks) == 12
+    assert de_vit.model_config["dedeit"]["embed_dim"] == 384
+    assert de_vit.model_config["deit_base_distilled_patch16_224"]["embed_dim"] == 768
+
+
+def test_statedict_abi():
+    c = json.load(open(os.path.join(GOLD, "statedict_keys.json")))
+    s = devit_amd.create_model("dedeit", num_classes=25)
+    t = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=25)
+    assert [[k, list(v.shape)] for k, v in s.state_dict().items()] == c["dedeit_keys"]
+    assert [[k, list(v.shape)] for k, v in t.state_dict().items()] == c["deitb_keys"]
+    assert len(list(s.buffers())) == 0                                             # no buffers (ensemble.py:229-238)
+    assert sorted(s.no_weight_decay()) == c["no_weight_decay"]
+    n_mlp = sum(1 for m in s.modules() if 'Mlp' in str(m) and 'Attention' not in str(m))
+    n_att = sum(1 for m in s.modules() if 'Attention' in str(m) and 'Mlp' not in str(m))
+    assert (n_mlp, n_att) == (c["n_mlp"], c["n_attn"]) == (12, 12)               # core/imp_rank.py:30,107
+    # positional copy as ensemble.py:192-200 does it: last four keys are the heads
+    assert list(s.state_dict())[-4:] == ["head.weight", "head.bias", "head_dist.weight", "head_dist.bias"]
+
+
+def test_gate_contract_and_drop_path_schedule():
+    m = devit_amd.create_model("dedeit", num_classes=10, drop_path_rate=0.1)
+    mlp, att = m.blocks[3].mlp, m.blocks[3].attn
+    assert mlp.hidden_features == 1536 and att.num_heads == 6
+    assert torch.equal(mlp.gate, torch.ones(1536)) and mlp.gate_on(torch.device("cpu")) is None
+    g = torch.ones(1536); g[::3] = 0
+    mlp.gate = g                                                                    # plain attribute assignment
+    assert mlp.gate is g and torch.equal(mlp.gate_on(torch.device("cpu")), g)
+    assert "gate" not in m.state_dict() and not any("gate" in k for k in m.state_dict())
+    dpr = [b.drop_prob for b in m.blocks]
+    assert dpr[0] == 0.0 and abs(dpr[-1] - 0.1) < 1e-7 and dpr == sorted(dpr)      # de_vit.py:175
+    m.train()
+    bps = [b.block_params.__func__ for b in m.blocks]                              # exists
+    assert len(bps) == 12
+    m.reset_classifier(7)
+    assert m.head.out_features == 7 and m.head_dist.out_features == 7
+
+
+def test_row_padding_and_splitk():
+    assert ops.pad_rows(50688) == 50688 and ops.pad_rows(396) == 512 and ops.pad_rows(1) == 256
+    assert ops.split_k_for(1536, 384, 792) >= 8
+    assert ops.split_k_for(384, 384, 792) <= 792
+    t = ops.rows_alloc(5, 8, torch.float32, torch.device("cpu"))
+    assert t.shape == (256, 8) and bool((t[5:] == 0).all())
+
+
+def test_flat_params_and_buckets():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 8), torch.nn.LayerNorm(8))
+    ref = {n: p.detach().clone() for n, p in m.named_parameters()}
+    flat = ddp.FlatParams(m)
+    assert flat.names[0] == "2.bias" and flat.names[-1] == "0.weight"              # reverse forward order
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), ref[n]) and p.grad is not None and float(p.grad.abs().sum()) == 0
+        assert p.data.data_ptr() >= flat.flat.data_ptr() and p.data_ptr() % 16 == 0
+    red = ddp.BucketedGradReducer(flat, bucket_bytes=1024)
+    covered = sorted(i for b in red.buckets for i in range(b[2], b[3] + 1))
+    assert covered == list(range(len(flat.params)))
+    assert red.buckets[0][0] == 0 and red.buckets[-1][1] == flat.numel
+    fired = []
+    red._launch = lambda b: fired.append(b) or red.launched.__setitem__(b, True)
+    for p in flat.params:                                                          # backward order
+        red.mark_ready([p])
+    assert fired == list(range(len(red.buckets)))                                  # buckets fire in order

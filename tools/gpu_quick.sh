@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/kernels.log 2>&1; tail -n 5 gpurun_out/kernels.log
+timeout 600 python tools/gemm_bench.py > gpurun_out/gemm_bench.log 2>&1; cat gpurun_out/gemm_bench.log
+DEVIT_GEMM_BM128_STAGES=4 timeout 600 python tools/gemm_bench.py 2>&1 | grep wgrad
+timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench.log 2>&1; tail -n 2 gpurun_out/bench.log
