@@ -71,11 +71,14 @@ struct AttnFwdArgs {
   float scale;
 };
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
+// Forward.  S^T = K Q^T puts the QUERY on the MFMA lane (col = lane & 15) and the keys in the accumulator
+// registers, so the row softmax is in-lane + two shuffles, and the bf16 P values of two key tiles are already
+// the B operand of O^T = V^T P (k-slot (g, j) = key 16*t(j>>2) + 4g + (j&3); V is read transposed with the
+// same key order).  P never touches LDS; each lane ends up with 4 consecutive d of its own query row.
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_img = smem;
   char* v_img = smem + IMG_BYTES;
-  char* p_all = smem + 2 * IMG_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -86,99 +89,85 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
   load_image(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
   __syncthreads();
 
-  char* pbuf = p_all + wave * (16 * PSTRIDE * 2);
   const float c2 = a.scale * 1.4426950408889634f;  // scores in log2 domain
   const float gate = a.head_gate ? a.head_gate[h] : 1.0f;
   const int ntile = (N + 15) >> 4;
-  const int lr = lane >> 4, lc = lane & 15;
+  const int g = lane >> 4, lc = lane & 15;
+  const int tq = (lane >> 2) & 3, tp = lane & 3;     // transposed-read row / column-quad of this lane
 
   for (int qt = wave; qt < ntile; qt += 4) {
-    const int q0 = qt * 16;
-    // Q fragments straight from global (row-major, d contiguous)
+    const int q = qt * 16 + lc;                      // this lane's query
     bf16x8 qf[2];
-    {
-      const int row = q0 + lc;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        qf[kk] = row < N ? *(const bf16x8*)(qbase + (size_t)row * rs + kk * 32 + lr * 8) : z;
-      }
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[kk] = q < N ? *(const bf16x8*)(qbase + (size_t)q * rs + kk * 32 + g * 8) : z;
     }
-    f32x4 s[MAXT];
+    f32x4 s[MAXT + 1];
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MAXT; ++t) {
+      s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) s[j] = mfma16(qf[kk], img_row_frag(k_img, j * 16, kk, lane), s[j]);
+      for (int kk = 0; kk < 2; ++kk) s[t] = mfma16(img_row_frag(k_img, t * 16, kk, lane), qf[kk], s[t]);
     }
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const bool ok = j * 16 + lc < N;
+    for (int t = 0; t < MAXT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[j][r] = ok ? s[j][r] * c2 : -INFINITY;
-        mx[r] = fmaxf(mx[r], s[j][r]);
+        s[t][r] = (t * 16 + g * 4 + r < N) ? s[t][r] * c2 : -INFINITY;
+        mx = fmaxf(mx, s[t][r]);
       }
-    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
-    }
-    float sum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
+    for (int t = 0; t < MAXT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(s[j][r] - mx[r]);
-        sum[r] += p;
-        *(__bf16*)(pbuf + (lr * 4 + r) * (PSTRIDE * 2) + (j * 16 + lc) * 2) = f2bf(p);
+        s[t][r] = exp2f(s[t][r] - mx);
+        sum += s[t][r];
       }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      *(__bf16*)(pbuf + (lr * 4 + r) * (PSTRIDE * 2) + (MAXT * 16 + lc) * 2) = f2bf(0.f);  // keys 208..223
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sum[r] += __shfl_xor(sum[r], o, 64);
-    }
-    if (a.lse && lc == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = q0 + lr * 4 + r;
-        if (q < N) a.lse[((size_t)b * a.H + h) * N + q] = (mx[r] + log2f(sum[r])) * 0.6931471805599453f;
-      }
-    }
-    // O = P V
+    s[MAXT] = (f32x4){0.f, 0.f, 0.f, 0.f};           // keys 208..223
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (a.lse && g == 0 && q < N) a.lse[((size_t)b * a.H + h) * N + q] = (mx + log2f(sum)) * 0.6931471805599453f;
+
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 7; ++ks) {
-      const bf16x8 pf = pbuf_row_frag(pbuf, 0, ks, lane);
+      const f32x4 p0 = s[2 * ks], p1 = s[2 * ks + 1];
+      const bf16x8 pf = {f2bf(p0[0]), f2bf(p0[1]), f2bf(p0[2]), f2bf(p0[3]),
+                         f2bf(p1[0]), f2bf(p1[1]), f2bf(p1[2]), f2bf(p1[3])};
+      const int r0 = ks * 32 + g * 4 + tq, r1 = r0 + 16;   // keys of tile 2ks / 2ks+1 for this lane group
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(pf, img_tr_frag(v_img, ks * 32, dt * 16, lane), o[dt]);
+      for (int dt = 0; dt < 4; ++dt) {
+        const int ch = dt * 2 + (tp >> 1), sub = (tp & 1) * 8;
+        const bf16x8 vf = cat8(lds_tr_read(v_img + img_off(r0, ch) + sub), lds_tr_read(v_img + img_off(r1, ch) + sub));
+        o[dt] = mfma16(vf, pf, o[dt]);               // O^T[d][q] += V^T[d][key] P^T[key][q]
+      }
     }
-    // stage the 16 x 64 output tile in this wave's P buffer (128-B rows) and store whole rows
+    if (q < N) {
+      const float sc = gate / sum;
+      __bf16* orow = a.out + ((size_t)b * N + q) * D + h * HD + g * 4;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *(__bf16*)(pbuf + (lr * 4 + r) * 128 + (dt * 16 + lc) * 2) = f2bf(o[dt][r] * (gate / sum[r]));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = lane + i * 64, row = idx >> 3, c = idx & 7;
-      const bf16x8 v = *(const bf16x8*)(pbuf + row * 128 + c * 16);
-      if (q0 + row < N) *(bf16x8*)(a.out + ((size_t)b * N + q0 + row) * D + h * HD + c * 8) = v;
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x4 ov = {f2bf(o[dt][0] * sc), f2bf(o[dt][1] * sc), f2bf(o[dt][2] * sc), f2bf(o[dt][3] * sc)};
+        *(bf16x4*)(orow + dt * 16) = ov;
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward.  Recomputes P from the saved log-sum-exp.  Per 32-query block: phase A computes
-// S and dP (key tiles split over waves) and writes P, dS (bf16) to LDS; phase B accumulates
-// dV += P^T dO, dK += dS^T Q in registers (each wave owns its key tiles for the whole kernel,
-// so no cross-workgroup reduction) and computes dQ = dS K for the block.
+// Backward.  Recomputes P from the saved log-sum-exp.  S and dP are computed with the KEY on the MFMA lane, so
+// their accumulators (two 16-query tiles = one 32-query block) are already the B operands of
+// dV^T += dO^T P and dK^T += Q^T dS: P never touches LDS and each wave keeps dK/dV of its own key tiles in
+// registers for the whole kernel (no cross-workgroup reduction, no atomics).  Only dS crosses LDS, once, stored
+// transposed ([key][q], 8-byte writes) and double-buffered (one barrier per query block), for
+// dQ^T = K^T dS^T.  Every gradient leaves as 8-byte (4 x bf16) stores along d.
 // ------------------------------------------------------------------------------------------
 struct AttnBwdArgs {
   const __bf16* qkv;
@@ -192,15 +181,26 @@ struct AttnBwdArgs {
   float scale;
 };
 
+constexpr int DST_STRIDE = 40;                       // bf16 per dS^T row: 32 queries + pad (80-B rows)
+constexpr int DST_BYTES = KROWS * DST_STRIDE * 2;    // 17920
+
+__device__ __forceinline__ void store_grad4(__bf16* dst, const __bf16* add, f32x4 v) {
+  if (add) {
+    const bf16x4 e = *(const bf16x4*)add;
+    v += (f32x4){bf2f(e[0]), bf2f(e[1]), bf2f(e[2]), bf2f(e[3])};
+  }
+  const bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+  *(bf16x4*)dst = o;
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_img = smem;
   char* k_img = smem + IMG_BYTES;
   char* v_img = smem + 2 * IMG_BYTES;
   char* do_img = smem + 3 * IMG_BYTES;
-  char* p_buf = smem + 4 * IMG_BYTES;
-  char* ds_buf = p_buf + 32 * PSTRIDE * 2;
-  float* lse2 = (float*)(ds_buf + 32 * PSTRIDE * 2);
+  char* dst_buf = smem + 4 * IMG_BYTES;              // 2 x [224 keys][DST_STRIDE]
+  float* lse2 = (float*)(dst_buf + 2 * DST_BYTES);
   float* delta = lse2 + KROWS;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -217,20 +217,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
   load_image(k_img, qbase + D, rs, N, 1.0f, tid);
   load_image(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
   load_image(do_img, dobase, (size_t)D, N, gate, tid);
-  // zero the P / dS buffers once: key columns of tile 13 (208..223) stay zero for the dQ k-steps
-  for (int i = tid; i < (2 * 32 * PSTRIDE * 2) / 16; i += 256) ((f32x4*)p_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // zero both dS^T buffers once: key rows of tiles that are never written (>= ntile) must read as 0 in dQ
+  for (int i = tid; i < 2 * DST_BYTES / 16; i += 256) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (tid < KROWS) {
     float l2 = 0.f, dl = 0.f;
     if (tid < N) {
       l2 = a.lse[((size_t)b * a.H + h) * N + tid] * 1.4426950408889634f;
       const __bf16* dr = dobase + (size_t)tid * D;
       const __bf16* orow = obase + (size_t)tid * D;
+      bf16x8 x[8], y[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const bf16x8 x = *(const bf16x8*)(dr + c * 8), y = *(const bf16x8*)(orow + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += bf2f(x[e]) * bf2f(y[e]);
+        x[c] = *(const bf16x8*)(dr + c * 8);
+        y[c] = *(const bf16x8*)(orow + c * 8);
       }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += bf2f(x[c][e]) * bf2f(y[c][e]);
     }
     lse2[tid] = l2;
     delta[tid] = dl;
@@ -238,10 +242,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
   __syncthreads();
 
   const float c2 = a.scale * 1.4426950408889634f;
-  const int ntile = (N + 15) >> 4;  // key tiles / q tiles that contain real tokens
-  const int lr = lane >> 4, lc = lane & 15;
+  const int ntile = (N + 15) >> 4;
+  const int g = lane >> 4, lc = lane & 15;
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
 
-  f32x4 dv[4][4], dk[4][4];
+  f32x4 dv[4][4], dk[4][4];    // [key tile of this wave][d tile]: rows d = 4g + r, col key = lc
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -252,112 +257,118 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
 
   const int nblk = (N + 31) >> 5;
   for (int qb = 0; qb < nblk; ++qb) {
-    // ---------------- phase A: P and dS for query rows [32 qb, 32 qb + 32)
+    char* dst = dst_buf + (qb & 1) * DST_BYTES;
+    // ---- S, dP for this wave's key tiles x the block's two query tiles; dV^T, dK^T straight from registers
+    bf16x8 qf[2][2], dof[2][2];
+    float l2[2][4], dl[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q0 = qb * 32 + i * 16;
-      bf16x8 qf[2], dof[2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        qf[kk] = img_row_frag(q_img, q0, kk, lane);
-        dof[kk] = img_row_frag(do_img, q0, kk, lane);
+        qf[i][kk] = img_row_frag(q_img, q0, kk, lane);
+        dof[i][kk] = img_row_frag(do_img, q0, kk, lane);
       }
-      float l2[4], dl[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        l2[r] = lse2[q0 + lr * 4 + r];
-        dl[r] = delta[q0 + lr * 4 + r];
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int kt = wave + t * 4;
-        if (kt < ntile) {
-          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            s = mfma16(qf[kk], img_row_frag(k_img, kt * 16, kk, lane), s);
-            dp = mfma16(dof[kk], img_row_frag(v_img, kt * 16, kk, lane), dp);
-          }
-          const bool kok = kt * 16 + lc < N;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = kok && (q0 + lr * 4 + r < N);
-            const float p = ok ? exp2f(s[r] * c2 - l2[r]) : 0.f;
-            const float d = p * (dp[r] - dl[r]) * a.scale;
-            const int off = (i * 16 + lr * 4 + r) * (PSTRIDE * 2) + (kt * 16 + lc) * 2;
-            *(__bf16*)(p_buf + off) = f2bf(p);
-            *(__bf16*)(ds_buf + off) = f2bf(d);
-          }
-        }
+        l2[i][r] = lse2[q0 + g * 4 + r];
+        dl[i][r] = delta[q0 + g * 4 + r];
       }
     }
-    __syncthreads();
-    // ---------------- phase B
+    // A operands of the dV^T / dK^T products: dO^T and Q^T with k-slot (g, j) = query 16 (j>>2) + 4g + (j&3)
+    bf16x8 dot[4], qtt[4];
+    {
+      const int r0 = qb * 32 + g * 4 + tq, r1 = r0 + 16;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int ch = dt * 2 + (tp >> 1), sub = (tp & 1) * 8;
+        dot[dt] = cat8(lds_tr_read(do_img + img_off(r0, ch) + sub), lds_tr_read(do_img + img_off(r1, ch) + sub));
+        qtt[dt] = cat8(lds_tr_read(q_img + img_off(r0, ch) + sub), lds_tr_read(q_img + img_off(r1, ch) + sub));
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int kt = wave + t * 4;
       if (kt < ntile) {
-        const bf16x8 pt = pbuf_tr_frag(p_buf, 0, kt * 16, lane);    // A[m = key][k = q]
-        const bf16x8 dst = pbuf_tr_frag(ds_buf, 0, kt * 16, lane);
+        bf16x8 kf[2], vf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          kf[kk] = img_row_frag(k_img, kt * 16, kk, lane);
+          vf[kk] = img_row_frag(v_img, kt * 16, kk, lane);
+        }
+        f32x4 pp[2], ds[2];
+        const bool kok = kt * 16 + lc < N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            sv = mfma16(qf[i][kk], kf[kk], sv);      // S[q][key], key on the lane
+            dp = mfma16(dof[i][kk], vf[kk], dp);     // dP[q][key]
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = kok && (qb * 32 + i * 16 + g * 4 + r < N);
+            const float p = ok ? exp2f(sv[r] * c2 - l2[i][r]) : 0.f;
+            pp[i][r] = p;
+            ds[i][r] = p * (dp[r] - dl[i][r]) * a.scale;
+          }
+          // dS^T[key][q = 16 i + 4 g + r], 4 consecutive queries = one 8-byte store
+          const bf16x4 dsb = {f2bf(ds[i][0]), f2bf(ds[i][1]), f2bf(ds[i][2]), f2bf(ds[i][3])};
+          *(bf16x4*)(dst + (kt * 16 + lc) * (DST_STRIDE * 2) + (i * 16 + g * 4) * 2) = dsb;
+        }
+        const bf16x8 pf = {f2bf(pp[0][0]), f2bf(pp[0][1]), f2bf(pp[0][2]), f2bf(pp[0][3]),
+                           f2bf(pp[1][0]), f2bf(pp[1][1]), f2bf(pp[1][2]), f2bf(pp[1][3])};
+        const bf16x8 dsf = {f2bf(ds[0][0]), f2bf(ds[0][1]), f2bf(ds[0][2]), f2bf(ds[0][3]),
+                            f2bf(ds[1][0]), f2bf(ds[1][1]), f2bf(ds[1][2]), f2bf(ds[1][3])};
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dv[t][dt] = mfma16(pt, img_tr_frag(do_img, qb * 32, dt * 16, lane), dv[t][dt]);
-          dk[t][dt] = mfma16(dst, img_tr_frag(q_img, qb * 32, dt * 16, lane), dk[t][dt]);
+          dv[t][dt] = mfma16(dot[dt], pf, dv[t][dt]);    // dV^T[d][key] += dO^T[d][q] P[q][key]
+          dk[t][dt] = mfma16(qtt[dt], dsf, dk[t][dt]);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
         }
       }
     }
+    __syncthreads();   // dS^T of this block complete (the other buffer is free again two blocks later)
     {
-      // dQ: wave -> q tile i = wave >> 1, d tiles {2 (wave & 1), +1}
+      // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: wave -> query tile i = wave >> 1, d tiles {2(wave&1), +1}
       const int i = wave >> 1, dt0 = (wave & 1) * 2;
       f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int ks = 0; ks < 7; ++ks) {
-        const bf16x8 dsf = pbuf_row_frag(ds_buf, i * 16, ks, lane);
+        const int kr = ks * 32 + g * 8 + tq;
+        // B[k = key][col = q]: transposed read of the dS^T image, columns q = 16 i + 4 tp ..
+        const char* pb = dst + kr * (DST_STRIDE * 2) + (i * 16 + tp * 4) * 2;
+        const bf16x8 bfr = cat8(lds_tr_read(pb), lds_tr_read(pb + 4 * DST_STRIDE * 2));
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dq[u] = mfma16(dsf, img_tr_frag(k_img, ks * 32, (dt0 + u) * 16, lane), dq[u]);
+        for (int u = 0; u < 2; ++u) dq[u] = mfma16(img_tr_frag(k_img, ks * 32, (dt0 + u) * 16, lane), bfr, dq[u]);
       }
+      const int q = qb * 32 + i * 16 + lc;
+      if (q < N) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = qb * 32 + i * 16 + lr * 4 + r;
-          if (q < N) {
-            const size_t o = ((size_t)b * N + q) * rs + h * HD + (dt0 + u) * 16 + lc;
-            float v = dq[u][r];
-            if (a.dqkv_add) v += bf2f(a.dqkv_add[o]);
-            a.dqkv[o] = f2bf(v);
-          }
+        for (int u = 0; u < 2; ++u) {
+          const size_t o = ((size_t)b * N + q) * rs + h * HD + (dt0 + u) * 16 + g * 4;
+          store_grad4(a.dqkv + o, a.dqkv_add ? a.dqkv_add + o : nullptr, dq[u]);
         }
+      }
     }
-    __syncthreads();
   }
-  // ---------------- dK, dV of this wave's key tiles
+  // ---- dK, dV of this wave's key tiles: lane = key, 4 consecutive d per register quad
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int kt = wave + t * 4;
-    if (kt < ntile) {
+    const int kt = wave + t * 4, key = kt * 16 + lc;
+    if (kt < ntile && key < N) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + lr * 4 + r;
-          if (key < N) {
-            const size_t o = ((size_t)b * N + key) * rs + h * HD + dt * 16 + lc;
-            float vk = dk[t][dt][r], vv = dv[t][dt][r];
-            if (a.dqkv_add) {
-              vk += bf2f(a.dqkv_add[o + D]);
-              vv += bf2f(a.dqkv_add[o + 2 * D]);
-            }
-            a.dqkv[o + D] = f2bf(vk);
-            a.dqkv[o + 2 * D] = f2bf(vv);
-          }
-        }
+      for (int dt = 0; dt < 4; ++dt) {
+        const size_t o = ((size_t)b * N + key) * rs + h * HD + dt * 16 + g * 4;
+        store_grad4(a.dqkv + o + D, a.dqkv_add ? a.dqkv_add + o + D : nullptr, dk[t][dt]);
+        store_grad4(a.dqkv + o + 2 * D, a.dqkv_add ? a.dqkv_add + o + 2 * D : nullptr, dv[t][dt]);
+      }
     }
   }
 }
 
-constexpr int FWD_LDS = 2 * IMG_BYTES + 4 * 16 * PSTRIDE * 2;                     // 87040
-constexpr int BWD_LDS = 4 * IMG_BYTES + 2 * 32 * PSTRIDE * 2 + 2 * KROWS * 4;     // 146176
+constexpr int FWD_LDS = 2 * IMG_BYTES;                                             // 57344: 2 workgroups per CU
+constexpr int BWD_LDS = 4 * IMG_BYTES + 2 * DST_BYTES + 2 * KROWS * 4;             // 152320
 
 }  // namespace
 

@@ -13,6 +13,8 @@
 // reads/writes global memory in whole 128/256-byte row segments.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "devit_common.h"
 
 namespace {
@@ -88,7 +90,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int t16, int kk, i
 
 #ifdef DEVIT_GEMM_STAMPS
 // Diagnostic build only (tools/build_stamps.sh): per-wave cycle totals of the K-loop segments.
-__device__ unsigned long long devit_gemm_stamps[4];
+__device__ unsigned long long devit_gemm_stamps[8];
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
@@ -104,6 +106,102 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One 64x64 fp32 staging tile (this wave's) -> fused epilogue -> global memory.  Two phases so that no load
+// waits behind the stores of an earlier row (vmcnt counts loads and stores in order on gfx950): first every
+// global input of the pass (residual / saved pre-activation / pos-embed rows) is fetched into registers, then all
+// rows are computed and stored back-to-back.  bf16 outputs: 8 columns (16 B) per lane; fp32: 4 columns (16 B).
+template <int KIND>
+__device__ __forceinline__ void epilogue_pass(const devit_epilogue& ep, const float* cw, int lane, int mw, int nw,
+                                              int m_lim, size_t ob) {
+  constexpr bool BF16_OUT = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
+  constexpr int COLS = BF16_OUT ? 8 : 4, LPR = 64 / COLS, RPI = 64 / LPR, ITERS = 64 / RPI, NV = COLS / 4;
+  const int col = (lane % LPR) * COLS, rl = lane / LPR;
+  const int n = nw + col;
+  f32x4 bias[NV], cs[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    bias[v] = ep.bias ? *(const f32x4*)(ep.bias + n + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    cs[v] = ep.colscale ? *(const f32x4*)(ep.colscale + n + v * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+  }
+  // ---- phase 1: global inputs of every row of the pass
+  f32x4 gin[KIND == DEVIT_EPI_RESIDUAL_F32 || KIND == DEVIT_EPI_PATCH_F32 ? ITERS : 1];
+  float rsc[KIND == DEVIT_EPI_RESIDUAL_F32 ? ITERS : 1];
+  bf16x8 pre[KIND == DEVIT_EPI_DGELU_BF16 ? ITERS : 1];
+  size_t offs[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int m = mw + it * RPI + rl;
+    const bool ok = m < m_lim;
+    size_t o = ob + (size_t)m * ep.ldc + n;
+    if (KIND == DEVIT_EPI_PATCH_F32) {
+      const int b = m / ep.patch_tokens, t = m - b * ep.patch_tokens, tok = ep.extra_tokens + t;
+      o = ((size_t)b * (ep.patch_tokens + ep.extra_tokens) + tok) * ep.ldc + n;
+      gin[it] = ok ? *(const f32x4*)(ep.pos + (size_t)tok * ep.ldc + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (KIND == DEVIT_EPI_RESIDUAL_F32) {
+      gin[it] = ok ? load_stream((const f32x4*)(ep.res + o)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      rsc[it] = (ok && ep.rowscale) ? ep.rowscale[m / ep.rows_per_scale] : 1.0f;
+    }
+    if (KIND == DEVIT_EPI_DGELU_BF16) {
+      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      pre[it] = ok ? load_stream((const bf16x8*)((const __bf16*)ep.aux_in + o)) : z;
+    }
+    offs[it] = o;
+  }
+  // ---- phase 2: compute + store
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int row = it * RPI + rl;
+    const bool ok = mw + row < m_lim;
+    const size_t o = offs[it];
+    f32x4 v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) v[u] = *(const f32x4*)(cw + row * 64 + col + u * 4) + bias[u];
+    if (KIND == DEVIT_EPI_STORE_F32) {
+      if (ok) *(f32x4*)((float*)ep.out + o) = v[0];
+    } else if (KIND == DEVIT_EPI_PATCH_F32) {
+      if (ok) *(f32x4*)((float*)ep.out + o) = v[0] + gin[it];
+    } else if (KIND == DEVIT_EPI_RESIDUAL_F32) {
+      if (ok) {
+        if (ep.aux) {
+          const bf16x4 pb = {f2bf(v[0][0]), f2bf(v[0][1]), f2bf(v[0][2]), f2bf(v[0][3])};
+          *(bf16x4*)((__bf16*)ep.aux + o) = pb;
+        }
+        *(f32x4*)((float*)ep.out + o) = gin[it] + rsc[it] * v[0];
+      }
+    } else {
+      float x[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] = v[c >> 2][c & 3];
+      if (KIND == DEVIT_EPI_GELU_BF16) {
+        if (ok && ep.aux) {
+          const bf16x8 pb = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(x[4]), f2bf(x[5]), f2bf(x[6]), f2bf(x[7])};
+          *(bf16x8*)((__bf16*)ep.aux + o) = pb;
+        }
+        if (ep.exact_gelu) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) x[c] = gelu_fwd<true>(x[c]) * cs[c >> 2][c & 3];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) x[c] = gelu_fwd<false>(x[c]) * cs[c >> 2][c & 3];
+        }
+      } else if (KIND == DEVIT_EPI_DGELU_BF16) {
+        if (ep.exact_gelu) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) x[c] = x[c] * cs[c >> 2][c & 3] * gelu_bwd<true>(bf2f(pre[it][c]));
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) x[c] = x[c] * cs[c >> 2][c & 3] * gelu_bwd<false>(bf2f(pre[it][c]));
+        }
+      }
+      if (ok) {
+        const bf16x8 ob8 = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(x[4]), f2bf(x[5]), f2bf(x[6]), f2bf(x[7])};
+        *(bf16x8*)((__bf16*)ep.out + o) = ob8;
+      }
+    }
+  }
 }
 
 // BM x BN x 64 tile, WAVES_M x WAVES_N waves (each (BM/WAVES_M) x (BN/WAVES_N)), NSTAGE-deep LDS ring filled
@@ -151,6 +249,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
   const __bf16* a_org = g.A + (size_t)bz * g.a_bs + (A_KM ? (size_t)m0 : (size_t)m0 * g.lda);
   const __bf16* b_org = g.B + (size_t)bz * g.b_bs + (B_KM ? (size_t)n0 : (size_t)n0 * g.ldb);
 
+#ifdef DEVIT_GEMM_STAMPS
+  const unsigned long long k_entry = stamp();
+#endif
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -169,6 +270,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
 
 #ifdef DEVIT_GEMM_STAMPS
   unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+  const unsigned long long k_loop0 = stamp();
 #endif
   for (int t = 0; t < nk; ++t) {
     STAMP(s0);
@@ -203,9 +305,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
 #endif
   }
 #ifdef DEVIT_GEMM_STAMPS
+  const unsigned long long k_loop1 = stamp();
   if (lane == 0) {
     atomicAdd(&devit_gemm_stamps[0], c_wait); atomicAdd(&devit_gemm_stamps[1], c_bar);
     atomicAdd(&devit_gemm_stamps[2], c_issue); atomicAdd(&devit_gemm_stamps[3], c_comp);
+    atomicAdd(&devit_gemm_stamps[4], k_loop0 - k_entry); atomicAdd(&devit_gemm_stamps[5], k_loop1 - k_loop0);
   }
 #endif
   __syncthreads();  // all fragment reads done before the ring is reused as the epilogue staging area
@@ -217,8 +321,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
   const size_t ob = (size_t)bz * ep.out_batch_stride;
   const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
   const int nw = n0 + wn * WN;
-#pragma unroll
-  for (int pass = 0; pass < MI / 4; ++pass) {
+  auto do_pass = [&](auto pass_c) {
+    constexpr int pass = decltype(pass_c)::value;
+
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -235,88 +340,34 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
       const float v = cw[row * 64 + lane];
       if (mw + row < m_lim) unsafeAtomicAdd(out + (size_t)(mw + row) * ep.ldc + nw + lane, v);
     }
-    continue;
+    return;
   }
 
-  const int col = (lane & 15) * 4;
-  const int n = nw + col;
-  f32x4 bias = {0.f, 0.f, 0.f, 0.f}, cs = {1.f, 1.f, 1.f, 1.f};
-  if (ep.bias) bias = *(const f32x4*)(ep.bias + n);
-  if (ep.colscale) cs = *(const f32x4*)(ep.colscale + n);
-
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 4 + (lane >> 4);
-    const int m = mw + row;
-    if (m >= m_lim) continue;
-    f32x4 v = *(const f32x4*)(cw + row * 64 + col);
-    v += bias;
-    const size_t o = ob + (size_t)m * ep.ldc + n;
-    switch (ep.kind) {
-      case DEVIT_EPI_STORE_BF16: {
-        bf16x4 ob = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        store8_stream((__bf16*)ep.out + o, ob);
-      } break;
-      case DEVIT_EPI_STORE_F32: {
-        store16_stream((float*)ep.out + o, v);
-      } break;
-      case DEVIT_EPI_GELU_BF16: {
-        if (ep.aux) {
-          bf16x4 pb = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          store8_stream((__bf16*)ep.aux + o, pb);
-        }
-        f32x4 a;
-        if (ep.exact_gelu) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) a[c] = gelu_fwd<true>(v[c]) * cs[c];
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) a[c] = gelu_fwd<false>(v[c]) * cs[c];
-        }
-        bf16x4 ob = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
-        store8_stream((__bf16*)ep.out + o, ob);
-      } break;
-      case DEVIT_EPI_DGELU_BF16: {
-        const bf16x4 pre = load_stream((const bf16x4*)((const __bf16*)ep.aux_in + o));
-        f32x4 a;
-        if (ep.exact_gelu) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) a[c] = v[c] * cs[c] * gelu_bwd<true>(bf2f(pre[c]));
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) a[c] = v[c] * cs[c] * gelu_bwd<false>(bf2f(pre[c]));
-        }
-        bf16x4 ob = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
-        store8_stream((__bf16*)ep.out + o, ob);
-      } break;
-      case DEVIT_EPI_RESIDUAL_F32: {
-        if (ep.aux) {
-          bf16x4 pb = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          store8_stream((__bf16*)ep.aux + o, pb);
-        }
-        const float rs = ep.rowscale ? ep.rowscale[m / ep.rows_per_scale] : 1.0f;
-        const f32x4 r = load_stream((const f32x4*)(ep.res + o));
-        store16_stream((float*)ep.out + o, r + rs * v);
-      } break;
-      case DEVIT_EPI_PATCH_F32: {
-        const int b = m / ep.patch_tokens, t = m - b * ep.patch_tokens;
-        const int tok = ep.extra_tokens + t;
-        const f32x4 pe = *(const f32x4*)(ep.pos + (size_t)tok * ep.ldc + n);
-        const size_t orow = (size_t)b * (ep.patch_tokens + ep.extra_tokens) + tok;
-        store16_stream((float*)ep.out + orow * ep.ldc + n, v + pe);
-      } break;
-      default:
-        break;
-    }
+  switch (ep.kind) {
+    case DEVIT_EPI_STORE_BF16: epilogue_pass<DEVIT_EPI_STORE_BF16>(ep, cw, lane, mw, nw, m_lim, ob); break;
+    case DEVIT_EPI_STORE_F32: epilogue_pass<DEVIT_EPI_STORE_F32>(ep, cw, lane, mw, nw, m_lim, ob); break;
+    case DEVIT_EPI_GELU_BF16: epilogue_pass<DEVIT_EPI_GELU_BF16>(ep, cw, lane, mw, nw, m_lim, ob); break;
+    case DEVIT_EPI_DGELU_BF16: epilogue_pass<DEVIT_EPI_DGELU_BF16>(ep, cw, lane, mw, nw, m_lim, ob); break;
+    case DEVIT_EPI_RESIDUAL_F32: epilogue_pass<DEVIT_EPI_RESIDUAL_F32>(ep, cw, lane, mw, nw, m_lim, ob); break;
+    case DEVIT_EPI_PATCH_F32: epilogue_pass<DEVIT_EPI_PATCH_F32>(ep, cw, lane, mw, nw, m_lim, ob); break;
+    default: break;
   }
-  }  // pass
+  };
+  do_pass(std::integral_constant<int, 0>());
+  if constexpr (MI > 4) do_pass(std::integral_constant<int, 1>());
+
+#ifdef DEVIT_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long k_end = stamp();
+  if (lane == 0) atomicAdd(&devit_gemm_stamps[6], k_end - k_loop1);
+#endif
 }
 
 #ifdef DEVIT_GEMM_STAMPS
 }  // namespace
 extern "C" int devit_debug_gemm_stamps(unsigned long long* out4, int reset) {
-  hipMemcpyFromSymbol(out4, HIP_SYMBOL(devit_gemm_stamps), 32);
-  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(devit_gemm_stamps), z, 32); }
+  hipMemcpyFromSymbol(out4, HIP_SYMBOL(devit_gemm_stamps), 64);
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(devit_gemm_stamps), z, 64); }
   return 0;
 }
 namespace {
@@ -335,8 +386,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   DEVIT_CHECK(M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0 && K % BK == 0 && batch >= 1, DEVIT_ERR_SHAPE,
               "devit_gemm_bf16: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, 128, 128, BK);
   DEVIT_CHECK(lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B) && aligned16(ep->out) &&
-                  ep->ldc % 4 == 0 && Aop->batch_stride % 8 == 0 && Bop->batch_stride % 8 == 0 &&
-                  ep->out_batch_stride % 4 == 0,
+                  ep->ldc % 8 == 0 && Aop->batch_stride % 8 == 0 && Bop->batch_stride % 8 == 0 &&
+                  ep->out_batch_stride % 8 == 0,
               DEVIT_ERR_ARG, "devit_gemm_bf16: pointers / strides must be 16-byte aligned");
   DEVIT_CHECK(ep->kind >= DEVIT_EPI_STORE_BF16 && ep->kind <= DEVIT_EPI_STORE_F32, DEVIT_ERR_ARG,
               "devit_gemm_bf16: bad epilogue kind %d", ep->kind);

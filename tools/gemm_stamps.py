@@ -13,17 +13,18 @@ def run(M, N, K, a_km, b_km, kind, label):
     a = torch.randn((K, M) if a_km else (M, K), device=dev).to(torch.bfloat16)
     b = (torch.randn((K, N) if b_km else (N, K), device=dev) * 0.02).to(torch.bfloat16)
     out = torch.zeros((M, N), dtype=torch.float32 if kind in (5, 6) else torch.bfloat16, device=dev)
-    buf = (C.c_ulonglong * 4)()
+    buf = (C.c_ulonglong * 8)()
     for i in range(3):
         ops.gemm(a, a.stride(0), a_km, b, b.stride(0), b_km, M, N, K, kind=kind, out=out, ldc=N, split_k=(16 if kind == 5 else 1))
         torch.cuda.synchronize()
         lib.devit_debug_gemm_stamps(buf, 1)
-    tot = sum(buf)
+    tot = sum(buf[:4])
     bm = 256 if M % 256 == 0 else 128
     waves = (M // bm) * (N // 128) * (bm // 32) * (16 if kind == 5 else 1)
     nk = K // 64 // (16 if kind == 5 else 1)
     print(f"{label:28s} wait {buf[0]/tot:5.1%} barrier {buf[1]/tot:5.1%} issue {buf[2]/tot:5.1%} compute {buf[3]/tot:5.1%}"
-          f"  cycles/K-step/wave {tot/waves/nk:7.0f}  (wait {buf[0]/waves/nk:5.0f} bar {buf[1]/waves/nk:5.0f} issue {buf[2]/waves/nk:5.0f} comp {buf[3]/waves/nk:5.0f})")
+          f"  cycles/K-step/wave {tot/waves/nk:7.0f}  (wait {buf[0]/waves/nk:5.0f} bar {buf[1]/waves/nk:5.0f} issue {buf[2]/waves/nk:5.0f} comp {buf[3]/waves/nk:5.0f})"
+          f" | per wave: prologue {buf[4]/waves:6.0f} loop {buf[5]/waves:7.0f} epilogue {buf[6]/waves:6.0f}")
 run(50688, 2304, 768, 0, 0, 0, "T qkv NT")
 run(50688, 1536, 384, 0, 0, 0, "S fc1 NT (store)")
 run(50688, 384, 1536, 0, 1, 0, "S fc1 dgrad")
