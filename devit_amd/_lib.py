@@ -42,7 +42,7 @@ SIGNATURES = {
     "devit_gemm_bf16": (_I, [C.POINTER(Operand), C.POINTER(Operand), _I, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
     "devit_layernorm_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "devit_layernorm_bwd_workspace": (_Z, [_I, _I]),
-    "devit_layernorm_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _Z, _P]),
+    "devit_layernorm_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "devit_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "devit_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "devit_im2row_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

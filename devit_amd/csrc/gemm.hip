@@ -108,15 +108,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// One 64x64 fp32 staging tile (this wave's) -> fused epilogue -> global memory.  Two phases so that no load
-// waits behind the stores of an earlier row (vmcnt counts loads and stores in order on gfx950): first every
-// global input of the pass (residual / saved pre-activation / pos-embed rows) is fetched into registers, then all
-// rows are computed and stored back-to-back.  bf16 outputs: 8 columns (16 B) per lane; fp32: 4 columns (16 B).
+// One 64x64 fp32 staging tile (this wave's) -> fused epilogue -> global memory.  Rows are processed in chunks of
+// CH iterations, each chunk in two phases so that no load waits behind the stores of an earlier row (vmcnt counts
+// loads and stores in order on gfx950): first the chunk's global inputs (residual / saved pre-activation /
+// pos-embed rows) are fetched into registers, then its rows are computed and stored back-to-back.  The chunk loop
+// stays rolled: the epilogue runs once per tile, so its code size is instruction-cache misses.
+// bf16 outputs: 8 columns (16 B) per lane; fp32: 4 columns (16 B).
 template <int KIND>
 __device__ __forceinline__ void epilogue_pass(const devit_epilogue& ep, const float* cw, int lane, int mw, int nw,
                                               int m_lim, size_t ob) {
   constexpr bool BF16_OUT = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
-  constexpr int COLS = BF16_OUT ? 8 : 4, LPR = 64 / COLS, RPI = 64 / LPR, ITERS = 64 / RPI, NV = COLS / 4;
+  constexpr int COLS = BF16_OUT ? 8 : 4, LPR = 64 / COLS, RPI = 64 / LPR, ITERS = 64 / RPI, NV = COLS / 4, CH = 4;
   const int col = (lane % LPR) * COLS, rl = lane / LPR;
   const int n = nw + col;
   f32x4 bias[NV], cs[NV];
@@ -125,80 +127,73 @@ __device__ __forceinline__ void epilogue_pass(const devit_epilogue& ep, const fl
     bias[v] = ep.bias ? *(const f32x4*)(ep.bias + n + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     cs[v] = ep.colscale ? *(const f32x4*)(ep.colscale + n + v * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
   }
-  // ---- phase 1: global inputs of every row of the pass
-  f32x4 gin[KIND == DEVIT_EPI_RESIDUAL_F32 || KIND == DEVIT_EPI_PATCH_F32 ? ITERS : 1];
-  float rsc[KIND == DEVIT_EPI_RESIDUAL_F32 ? ITERS : 1];
-  bf16x8 pre[KIND == DEVIT_EPI_DGELU_BF16 ? ITERS : 1];
-  size_t offs[ITERS];
+#pragma unroll 1
+  for (int c0 = 0; c0 < ITERS; c0 += CH) {
+    // ---- phase 1: global inputs of the chunk
+    f32x4 gin[CH];
+    float rsc[CH];
+    bf16x8 pre[CH];
+    size_t offs[CH];
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int m = mw + it * RPI + rl;
-    const bool ok = m < m_lim;
-    size_t o = ob + (size_t)m * ep.ldc + n;
-    if (KIND == DEVIT_EPI_PATCH_F32) {
-      const int b = m / ep.patch_tokens, t = m - b * ep.patch_tokens, tok = ep.extra_tokens + t;
-      o = ((size_t)b * (ep.patch_tokens + ep.extra_tokens) + tok) * ep.ldc + n;
-      gin[it] = ok ? *(const f32x4*)(ep.pos + (size_t)tok * ep.ldc + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if (KIND == DEVIT_EPI_RESIDUAL_F32) {
-      gin[it] = ok ? load_stream((const f32x4*)(ep.res + o)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      rsc[it] = (ok && ep.rowscale) ? ep.rowscale[m / ep.rows_per_scale] : 1.0f;
-    }
-    if (KIND == DEVIT_EPI_DGELU_BF16) {
-      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      pre[it] = ok ? load_stream((const bf16x8*)((const __bf16*)ep.aux_in + o)) : z;
-    }
-    offs[it] = o;
-  }
-  // ---- phase 2: compute + store
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int row = it * RPI + rl;
-    const bool ok = mw + row < m_lim;
-    const size_t o = offs[it];
-    f32x4 v[NV];
-#pragma unroll
-    for (int u = 0; u < NV; ++u) v[u] = *(const f32x4*)(cw + row * 64 + col + u * 4) + bias[u];
-    if (KIND == DEVIT_EPI_STORE_F32) {
-      if (ok) *(f32x4*)((float*)ep.out + o) = v[0];
-    } else if (KIND == DEVIT_EPI_PATCH_F32) {
-      if (ok) *(f32x4*)((float*)ep.out + o) = v[0] + gin[it];
-    } else if (KIND == DEVIT_EPI_RESIDUAL_F32) {
-      if (ok) {
-        if (ep.aux) {
-          const bf16x4 pb = {f2bf(v[0][0]), f2bf(v[0][1]), f2bf(v[0][2]), f2bf(v[0][3])};
-          *(bf16x4*)((__bf16*)ep.aux + o) = pb;
-        }
-        *(f32x4*)((float*)ep.out + o) = gin[it] + rsc[it] * v[0];
+    for (int u = 0; u < CH; ++u) {
+      const int m = mw + (c0 + u) * RPI + rl;
+      const bool ok = m < m_lim;
+      size_t o = ob + (size_t)m * ep.ldc + n;
+      if (KIND == DEVIT_EPI_PATCH_F32) {
+        const int b = m / ep.patch_tokens, t = m - b * ep.patch_tokens, tok = ep.extra_tokens + t;
+        o = ((size_t)b * (ep.patch_tokens + ep.extra_tokens) + tok) * ep.ldc + n;
+        gin[u] = ok ? *(const f32x4*)(ep.pos + (size_t)tok * ep.ldc + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-    } else {
-      float x[8];
+      if (KIND == DEVIT_EPI_RESIDUAL_F32) {
+        gin[u] = ok ? load_stream((const f32x4*)(ep.res + o)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        rsc[u] = (ok && ep.rowscale) ? ep.rowscale[m / ep.rows_per_scale] : 1.0f;
+      }
+      if (KIND == DEVIT_EPI_DGELU_BF16) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        pre[u] = ok ? load_stream((const bf16x8*)((const __bf16*)ep.aux_in + o)) : z;
+      }
+      offs[u] = o;
+    }
+    // ---- phase 2: compute + store
 #pragma unroll
-      for (int c = 0; c < 8; ++c) x[c] = v[c >> 2][c & 3];
-      if (KIND == DEVIT_EPI_GELU_BF16) {
-        if (ok && ep.aux) {
-          const bf16x8 pb = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(x[4]), f2bf(x[5]), f2bf(x[6]), f2bf(x[7])};
-          *(bf16x8*)((__bf16*)ep.aux + o) = pb;
+    for (int u = 0; u < CH; ++u) {
+      const int row = (c0 + u) * RPI + rl;
+      const bool ok = mw + row < m_lim;
+      const size_t o = offs[u];
+      f32x4 v[NV];
+#pragma unroll
+      for (int w = 0; w < NV; ++w) v[w] = *(const f32x4*)(cw + row * 64 + col + w * 4) + bias[w];
+      if (KIND == DEVIT_EPI_STORE_F32) {
+        if (ok) *(f32x4*)((float*)ep.out + o) = v[0];
+      } else if (KIND == DEVIT_EPI_PATCH_F32) {
+        if (ok) *(f32x4*)((float*)ep.out + o) = v[0] + gin[u];
+      } else if (KIND == DEVIT_EPI_RESIDUAL_F32) {
+        if (ok) {
+          if (ep.aux) {
+            const bf16x4 pb = {f2bf(v[0][0]), f2bf(v[0][1]), f2bf(v[0][2]), f2bf(v[0][3])};
+            *(bf16x4*)((__bf16*)ep.aux + o) = pb;
+          }
+          *(f32x4*)((float*)ep.out + o) = gin[u] + rsc[u] * v[0];
         }
-        if (ep.exact_gelu) {
+      } else {
+        float x[8];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) x[c] = gelu_fwd<true>(x[c]) * cs[c >> 2][c & 3];
-        } else {
+        for (int c = 0; c < 8; ++c) x[c] = v[c >> 2][c & 3];
+        if (KIND == DEVIT_EPI_GELU_BF16) {
+          if (ok && ep.aux) {
+            const bf16x8 pb = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(x[4]), f2bf(x[5]), f2bf(x[6]), f2bf(x[7])};
+            *(bf16x8*)((__bf16*)ep.aux + o) = pb;
+          }
 #pragma unroll
           for (int c = 0; c < 8; ++c) x[c] = gelu_fwd<false>(x[c]) * cs[c >> 2][c & 3];
-        }
-      } else if (KIND == DEVIT_EPI_DGELU_BF16) {
-        if (ep.exact_gelu) {
+        } else if (KIND == DEVIT_EPI_DGELU_BF16) {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) x[c] = x[c] * cs[c >> 2][c & 3] * gelu_bwd<true>(bf2f(pre[it][c]));
-        } else {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) x[c] = x[c] * cs[c >> 2][c & 3] * gelu_bwd<false>(bf2f(pre[it][c]));
+          for (int c = 0; c < 8; ++c) x[c] = x[c] * cs[c >> 2][c & 3] * gelu_bwd<false>(bf2f(pre[u][c]));
         }
-      }
-      if (ok) {
-        const bf16x8 ob8 = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(x[4]), f2bf(x[5]), f2bf(x[6]), f2bf(x[7])};
-        *(bf16x8*)((__bf16*)ep.out + o) = ob8;
+        if (ok) {
+          const bf16x8 ob8 = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(x[4]), f2bf(x[5]), f2bf(x[6]), f2bf(x[7])};
+          *(bf16x8*)((__bf16*)ep.out + o) = ob8;
+        }
       }
     }
   }
@@ -207,7 +202,7 @@ __device__ __forceinline__ void epilogue_pass(const devit_epilogue& ep, const fl
 // BM x BN x 64 tile, WAVES_M x WAVES_N waves (each (BM/WAVES_M) x (BN/WAVES_N)), NSTAGE-deep LDS ring filled
 // by LDS-DMA.  One raw barrier per K-step; the DMA of the NSTAGE-2 newest stages stays in flight across it
 // (counted vmcnt), cdna_hip_programming.md "Pipelining across barriers".
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool A_KM, bool B_KM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool A_KM, bool B_KM, int KIND>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -334,23 +329,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
   // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
   const int mw = m0 + wm * WM + pass * 64;
 
-  if (ep.kind == DEVIT_EPI_ATOMIC_F32) {
+  if constexpr (KIND == DEVIT_EPI_ATOMIC_F32) {
     float* out = (float*)ep.out + ob;
     for (int row = 0; row < 64; ++row) {
       const float v = cw[row * 64 + lane];
       if (mw + row < m_lim) unsafeAtomicAdd(out + (size_t)(mw + row) * ep.ldc + nw + lane, v);
     }
-    return;
-  }
-
-  switch (ep.kind) {
-    case DEVIT_EPI_STORE_BF16: epilogue_pass<DEVIT_EPI_STORE_BF16>(ep, cw, lane, mw, nw, m_lim, ob); break;
-    case DEVIT_EPI_STORE_F32: epilogue_pass<DEVIT_EPI_STORE_F32>(ep, cw, lane, mw, nw, m_lim, ob); break;
-    case DEVIT_EPI_GELU_BF16: epilogue_pass<DEVIT_EPI_GELU_BF16>(ep, cw, lane, mw, nw, m_lim, ob); break;
-    case DEVIT_EPI_DGELU_BF16: epilogue_pass<DEVIT_EPI_DGELU_BF16>(ep, cw, lane, mw, nw, m_lim, ob); break;
-    case DEVIT_EPI_RESIDUAL_F32: epilogue_pass<DEVIT_EPI_RESIDUAL_F32>(ep, cw, lane, mw, nw, m_lim, ob); break;
-    case DEVIT_EPI_PATCH_F32: epilogue_pass<DEVIT_EPI_PATCH_F32>(ep, cw, lane, mw, nw, m_lim, ob); break;
-    default: break;
+  } else {
+    epilogue_pass<KIND>(ep, cw, lane, mw, nw, m_lim, ob);
   }
   };
   do_pass(std::integral_constant<int, 0>());
@@ -404,6 +390,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
                 DEVIT_ERR_ARG,
                 "PATCH: pos / tokens");
   if (ep->kind == DEVIT_EPI_DGELU_BF16) DEVIT_CHECK(ep->aux_in != nullptr, DEVIT_ERR_ARG, "DGELU: aux_in");
+  DEVIT_CHECK(ep->exact_gelu == 0, DEVIT_ERR_ARG, "devit_gemm_bf16: exact_gelu=1 (erff) is not built; the fused GELU uses a "
+              "1.5e-7-accurate erf");
 
   GemmArgs g;
   g.A = (const __bf16*)A; g.B = (const __bf16*)B;
@@ -433,33 +421,43 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   DEVIT_CHECK(nwg < (1ll << 31), DEVIT_ERR_SHAPE, "devit_gemm_bf16: grid too large");
   hipStream_t s = (hipStream_t)stream;
   const int variant = (a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0);
-#define DEVIT_LAUNCH_GEMM(BM_, BN_, WMM_, WNN_, NS_)                                                           \
+#define DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_)                                          \
   do {                                                                                                         \
     constexpr int ring = NS_ * (BM_ + BN_) * 128, stagebytes = WMM_ * WNN_ * 16384;                            \
     constexpr int lds = ring > stagebytes ? ring : stagebytes;                                                 \
-    static bool attr[4] = {false, false, false, false};                                                        \
-    const void* fn = variant == 0   ? (const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, false, false>        \
-                     : variant == 1 ? (const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, false, true>         \
-                     : variant == 2 ? (const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, true, false>         \
-                                    : (const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, true, true>;         \
-    if (!attr[variant]) {                                                                                      \
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                 \
+    static bool attr = false;                                                                                  \
+    if (!attr) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_>, \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
       DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
-      attr[variant] = true;                                                                                    \
+      attr = true;                                                                                             \
     }                                                                                                          \
-    dim3 grid((unsigned)nwg), block(WMM_* WNN_ * 64);                                                          \
-    if (variant == 0)                                                                                          \
-      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, false, false>), grid, block, lds, s, g);      \
-    else if (variant == 1)                                                                                     \
-      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, false, true>), grid, block, lds, s, g);       \
-    else if (variant == 2)                                                                                     \
-      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, true, false>), grid, block, lds, s, g);       \
-    else                                                                                                       \
-      hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, true, true>), grid, block, lds, s, g);        \
+    hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_>), dim3((unsigned)nwg),       \
+                       dim3(WMM_* WNN_ * 64), lds, s, g);                                                      \
+  } while (0)
+  // the (layout, epilogue) pairs the DeViT path uses; anything else is DEVIT_ERR_ARG
+#define DEVIT_LAUNCH_GEMM(BM_, BN_, WMM_, WNN_, NS_)                                                           \
+  do {                                                                                                         \
+    const int key = variant * 16 + ep->kind;                                                                   \
+    switch (key) {                                                                                             \
+      case 0 * 16 + DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_STORE_BF16); break;       \
+      case 0 * 16 + DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_STORE_F32); break;         \
+      case 0 * 16 + DEVIT_EPI_GELU_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_GELU_BF16); break;         \
+      case 0 * 16 + DEVIT_EPI_RESIDUAL_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_RESIDUAL_F32); break;   \
+      case 0 * 16 + DEVIT_EPI_PATCH_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_PATCH_F32); break;         \
+      case 1 * 16 + DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_STORE_BF16); break;        \
+      case 1 * 16 + DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_STORE_F32); break;          \
+      case 1 * 16 + DEVIT_EPI_DGELU_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_DGELU_BF16); break;        \
+      case 3 * 16 + DEVIT_EPI_ATOMIC_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, true, true, DEVIT_EPI_ATOMIC_F32); break;         \
+      case 3 * 16 + DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, true, true, DEVIT_EPI_STORE_F32); break;           \
+      default:                                                                                                 \
+        DEVIT_CHECK(false, DEVIT_ERR_ARG, "devit_gemm_bf16: layout %d with epilogue %d is not instantiated", variant, ep->kind); \
+    }                                                                                                          \
   } while (0)
   if (cfg == 3) DEVIT_LAUNCH_GEMM(256, 256, 2, 4, 2);
   else if (cfg == 2) DEVIT_LAUNCH_GEMM(256, 128, 4, 2, 3);
   else DEVIT_LAUNCH_GEMM(128, 128, 2, 2, 2);
+#undef DEVIT_LAUNCH_ONE
 #undef DEVIT_LAUNCH_GEMM
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;

@@ -86,80 +86,110 @@ struct LnBwdArgs {
   __bf16* dx_bf16;      // optional bf16 copy of rowscale * dx (branch gradient for the next GEMMs)
   const float* rowscale;
   int rows_per_scale;
-  float* partial;       // [grid][2][D] column partial sums (dgamma, dbeta)
+  float* partial;       // [grid][3][D] column partial sums (dgamma, dbeta, colsum of dx_bf16)
   int rows, D, in_group, in_stride, dy_is_f32;
 };
 
+// Half a wave (32 lanes x 4*NV columns) per token row, two rows per wave pass: 16-byte loads of x / dres and 8-byte
+// loads of the bf16 dy keep ~2.5 KB per wave in flight (HBM-bound kernel).
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
-  __shared__ float red[4][2][LN_MAX_NV * 128];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wave_global = blockIdx.x * 4 + wv;
-  const int nwaves = gridDim.x * 4;
-  f32x2 gm[NV], dg[NV], db[NV];
+  __shared__ float red[4][3][NV * 128];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+  const int slot = (blockIdx.x * 4 + wv) * 2 + half;       // half-wave id
+  const int nslots = gridDim.x * 8;
+  f32x4 gm[NV], dg[NV], db[NV], dsum[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    gm[v] = *(const f32x2*)(a.gamma + v * 128 + lane * 2);
-    dg[v] = (f32x2){0.f, 0.f};
-    db[v] = (f32x2){0.f, 0.f};
+    gm[v] = *(const f32x4*)(a.gamma + v * 128 + hl * 4);
+    dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dsum[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const float invD = 1.0f / (float)a.D;
-  for (int r = wave_global; r < a.rows; r += nwaves) {
-    const size_t pr = ln_in_row(r, a.in_group, a.in_stride);
+  const int nit = (a.rows + nslots - 1) / nslots;           // wave-uniform trip count (shuffles need all lanes)
+  for (int it = 0; it < nit; ++it) {
+    const int r = slot + it * nslots;
+    const bool live = r < a.rows;
+    const size_t pr = ln_in_row(live ? r : 0, a.in_group, a.in_stride);
     const float* xr = a.x + pr * a.D;
-    const float mu = a.mean[r], rs = a.rstd[r];
-    f32x2 xh[NV], g[NV];
+    const float mu = live ? a.mean[r] : 0.f, rs = live ? a.rstd[r] : 0.f;
+    f32x4 xh[NV], g[NV], dyv[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int c = v * 128 + lane * 2;
-      const f32x2 xv = *(const f32x2*)(xr + c);
-      f32x2 dyv;
-      if (a.dy_is_f32) {
-        dyv = *(const f32x2*)((const float*)a.dy + (size_t)r * a.D + c);
-      } else {
-        const bf16x2 t = *(const bf16x2*)((const __bf16*)a.dy + (size_t)r * a.D + c);
-        dyv = (f32x2){bf2f(t[0]), bf2f(t[1])};
+      const int c = v * 128 + hl * 4;
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+      dyv[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        xv = load_stream((const f32x4*)(xr + c));
+        if (a.dy_is_f32) {
+          dyv[v] = load_stream((const f32x4*)((const float*)a.dy + (size_t)r * a.D + c));
+        } else {
+          const bf16x4 t = load_stream((const bf16x4*)((const __bf16*)a.dy + (size_t)r * a.D + c));
+          dyv[v] = (f32x4){bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        }
       }
-      xh[v] = (f32x2){(xv[0] - mu) * rs, (xv[1] - mu) * rs};
-      g[v] = dyv * gm[v];
-      dg[v] += dyv * xh[v];
-      db[v] += dyv;
-      s1 += g[v][0] + g[v][1];
-      s2 += g[v][0] * xh[v][0] + g[v][1] * xh[v][1];
-    }
-    const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
-    const float rsc = (a.dx_bf16 && a.rowscale) ? a.rowscale[pr / a.rows_per_scale] : 1.0f;
+      xh[v] = (xv - mu) * rs;
+      g[v] = dyv[v] * gm[v];
+      dg[v] += dyv[v] * xh[v];
+      db[v] += dyv[v];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const size_t o = pr * a.D + v * 128 + lane * 2;
-      f32x2 d = (f32x2){rs * (g[v][0] - m1 - xh[v][0] * m2), rs * (g[v][1] - m1 - xh[v][1] * m2)};
-      if (a.dres) d += *(const f32x2*)(a.dres + o);
-      *(f32x2*)(a.dx + o) = d;
-      if (a.dx_bf16) {
-        bf16x2 ob = {f2bf(d[0] * rsc), f2bf(d[1] * rsc)};
-        *(bf16x2*)(a.dx_bf16 + o) = ob;
+      for (int e = 0; e < 4; ++e) {
+        s1 += g[v][e];
+        s2 += g[v][e] * xh[v][e];
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    const float m1 = s1 * invD, m2 = s2 * invD;
+    if (live) {
+      const float rsc = (a.dx_bf16 && a.rowscale) ? a.rowscale[pr / a.rows_per_scale] : 1.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const size_t o = pr * a.D + v * 128 + hl * 4;
+        f32x4 d = rs * (g[v] - m1 - xh[v] * m2);
+        if (a.dres) d += load_stream((const f32x4*)(a.dres + o));
+        *(f32x4*)(a.dx + o) = d;
+        if (a.dx_bf16) {
+          const bf16x4 ob = {f2bf(d[0] * rsc), f2bf(d[1] * rsc), f2bf(d[2] * rsc), f2bf(d[3] * rsc)};
+          *(bf16x4*)(a.dx_bf16 + o) = ob;
+          dsum[v] += (f32x4){bf2f(ob[0]), bf2f(ob[1]), bf2f(ob[2]), bf2f(ob[3])};
+        }
       }
     }
   }
-  // block reduction of the column sums -> partial[block][{dgamma,dbeta}][D]
+  // block reduction of the column sums -> partial[block][{dgamma, dbeta, colsum(dx_bf16)}][D]
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    *(f32x2*)&red[wv][0][v * 128 + lane * 2] = dg[v];
-    *(f32x2*)&red[wv][1][v * 128 + lane * 2] = db[v];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {      // the two half-waves hold the same columns
+      dg[v][e] += __shfl_xor(dg[v][e], 32, 64);
+      db[v][e] += __shfl_xor(db[v][e], 32, 64);
+      dsum[v][e] += __shfl_xor(dsum[v][e], 32, 64);
+    }
+    if (half == 0) {
+      *(f32x4*)&red[wv][0][v * 128 + hl * 4] = dg[v];
+      *(f32x4*)&red[wv][1][v * 128 + hl * 4] = db[v];
+      *(f32x4*)&red[wv][2][v * 128 + hl * 4] = dsum[v];
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * a.D; i += 256) {
+  for (int i = threadIdx.x; i < 3 * a.D; i += 256) {
     const int which = i / a.D, c = i - which * a.D;
-    a.partial[((size_t)blockIdx.x * 2 + which) * a.D + c] =
+    a.partial[((size_t)blockIdx.x * 3 + which) * a.D + c] =
         red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
   }
 }
 
-// out[c] (+)= sum_p partial[p][c]   (deterministic order; 32 columns x 8 part-groups per block)
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* partial, int nparts, int ncols,
-                                                              float* out0, float* out1, int D, int accumulate) {
+// out_k[c] (+)= sum_p partial[p][k][c], k = 0..2  (deterministic order; 32 columns x 8 part-groups per block)
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* partial, int nparts, int D, float* out0,
+                                                              float* out1, float* out2, int accumulate) {
   __shared__ float red[8][32];
+  const int ncols = 3 * D;
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
@@ -171,8 +201,8 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* parti
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t += red[i][cl];
-    float* dst = c < D ? out0 + c : out1 + (c - D);
-    *dst = accumulate ? *dst + t : t;
+    float* dst = c < D ? out0 + c : (c < 2 * D ? out1 + (c - D) : (out2 ? out2 + (c - 2 * D) : nullptr));
+    if (dst) *dst = accumulate ? *dst + t : t;
   }
 }
 
@@ -207,23 +237,25 @@ extern "C" int devit_layernorm_fwd(const float* x, int rows, int D, int in_group
   return DEVIT_OK;
 }
 
+static int ln_bwd_grid(int rows) { return rows < 8 * 1024 ? (rows + 7) / 8 : 1024; }
+
 extern "C" size_t devit_layernorm_bwd_workspace(int rows, int D) {
-  const int grid = rows < 4 * 512 ? (rows + 3) / 4 : 512;
-  return (size_t)grid * 2 * D * sizeof(float);
+  return (size_t)ln_bwd_grid(rows) * 3 * D * sizeof(float);
 }
 
 extern "C" int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows, int D, int in_group,
                                    int in_stride, const float* mean, const float* rstd, const float* gamma,
                                    const float* dres, float* dx, void* dx_bf16, const float* rowscale,
-                                   int rows_per_scale, float* dgamma, float* dbeta, int accumulate, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+                                   int rows_per_scale, float* dgamma, float* dbeta, float* dx_bf16_colsum,
+                                   int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   DEVIT_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, DEVIT_ERR_ARG,
               "devit_layernorm_bwd: null pointer");
   DEVIT_CHECK(rows > 0 && D % 128 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: D=%d", D);
   DEVIT_CHECK(workspace_bytes >= devit_layernorm_bwd_workspace(rows, D), DEVIT_ERR_ARG,
               "devit_layernorm_bwd: workspace too small");
   DEVIT_CHECK(!rowscale || rows_per_scale > 0, DEVIT_ERR_ARG, "devit_layernorm_bwd: rows_per_scale");
-  const int grid = rows < 4 * 512 ? (rows + 3) / 4 : 512;
+  DEVIT_CHECK(!dx_bf16_colsum || dx_bf16, DEVIT_ERR_ARG, "devit_layernorm_bwd: dx_bf16_colsum needs dx_bf16");
+  const int grid = ln_bwd_grid(rows);
   LnBwdArgs a{dy, x, mean, rstd, gamma, dres, dx, (__bf16*)dx_bf16, rowscale, rows_per_scale,
               (float*)workspace, rows, D, in_group, in_stride, dy_is_f32};
   int rc = dispatch_nv<LnBwdArgs>(D, [&](auto nv) {
@@ -231,8 +263,8 @@ extern "C" int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x
   });
   DEVIT_CHECK(rc == 0, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: unsupported D=%d", D);
   DEVIT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, grid, 2 * D, dgamma, dbeta, D, accumulate);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((3 * D + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, grid, D, dgamma, dbeta, dx_bf16_colsum, accumulate);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }

@@ -129,12 +129,12 @@ def layernorm_fwd(x2d, rows, D, gamma, beta, eps, *, y_bf16=None, y_f32=None, me
 
 
 def layernorm_bwd(dy, dy_is_f32, x2d, rows, D, mean, rstd, gamma, dres, dx, dx_bf16, rowscale, rows_per_scale, dgamma,
-                  dbeta, in_group=0, in_stride=0):
+                  dbeta, in_group=0, in_stride=0, gsum=None):
     nbytes = L.load().devit_layernorm_bwd_workspace(rows, D)
     ws = workspace(x2d.device, nbytes)
     call("devit_layernorm_bwd", ptr(dy), int(dy_is_f32), ptr(x2d), rows, D, in_group, in_stride, ptr(mean), ptr(rstd),
-         ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(rowscale), rows_per_scale, ptr(dgamma), ptr(dbeta), 1,
-         ptr(ws), ws.numel(), stream_ptr())
+         ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(rowscale), rows_per_scale, ptr(dgamma), ptr(dbeta),
+         ptr(gsum), 1, ptr(ws), ws.numel(), stream_ptr())
 
 
 def cast_bf16(src, dst=None):
@@ -223,7 +223,7 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att):
     return x2o, qkv, att, s
 
 
-def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g):
+def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, prev_fc2_b=None, g2_bias_done=False):
     """dx: fp32 [B,N,D] grad of the block output; g2: bf16 [Mp, D] = bf16(dp2 * dx).
     Returns (dx_in fp32 [B,N,D], g_prev bf16 [Mp,D] = bf16(prev_dp2 * dx_in) or None)."""
     B, N, D = dx.shape
@@ -233,20 +233,21 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g):
     dh_pre = rows_alloc(M, Hd, BF16, dev)
     linear_dgrad(g2, bp.fc2_w16, M, out=dh_pre, kind=L.EPI_DGELU_BF16, colscale=bp.neuron_gate, aux_in=s["h_pre"],
                  exact_gelu=cfg.exact_gelu)
-    linear_wgrad(g2, s["h"], grad_buf(bp.fc2_w), grad_buf(bp.fc2_b), M)
+    linear_wgrad(g2, s["h"], grad_buf(bp.fc2_w), None if g2_bias_done else grad_buf(bp.fc2_b), M)
     dln2 = rows_alloc(M, D, BF16, dev)
     linear_dgrad(dh_pre, bp.fc1_w16, M, out=dln2)
     linear_wgrad(dh_pre, s["ln2"], grad_buf(bp.fc1_w), grad_buf(bp.fc1_b), M)
     dx1 = torch.empty((B, N, D), dtype=F32, device=dev)
     g1 = rows_alloc(M, D, BF16, dev)
+    fuse_pb = datt is None        # proj bias gradient = column sums of g1, produced by the same LN-bwd launch
     layernorm_bwd(dln2, False, s["x1"].view(M, D), M, D, s["mean2"], s["rstd2"], bp.n2w, dx.view(M, D), dx1.view(M, D),
-                  g1, s["dp1"], N, grad_buf(bp.n2w), grad_buf(bp.n2b))
+                  g1, s["dp1"], N, grad_buf(bp.n2w), grad_buf(bp.n2b), gsum=grad_buf(bp.proj_b) if fuse_pb else None)
     # ---- attention branch: x1 = x + dp1 * proj(gate * attn(qkv(ln1)))
     if datt is not None:  # gradient flowing into the exposed 'attention' output (pre-residual, post-proj)
         g1 = g1 + _pad_like(datt, g1)
     dattn = rows_alloc(M, D, BF16, dev)
     linear_dgrad(g1, bp.proj_w16, M, out=dattn)
-    linear_wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), grad_buf(bp.proj_b), M)
+    linear_wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), None if fuse_pb else grad_buf(bp.proj_b), M)
     dqkv = rows_alloc(M, 3 * D, BF16, dev)
     call("devit_attn_bwd", ptr(s["qkv"]), ptr(s["attn_o"]), ptr(dattn), ptr(s["lse"]), ptr(bp.head_gate),
          ptr(dqkv_add), ptr(dqkv), B, N, H, D // H, (D // H) ** -0.5, stream_ptr())
@@ -256,7 +257,8 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g):
     dx0 = torch.empty((B, N, D), dtype=F32, device=dev)
     g_prev = rows_alloc(M, D, BF16, dev) if want_prev_g else None
     layernorm_bwd(dln1, False, s["x"].view(M, D), M, D, s["mean1"], s["rstd1"], bp.n1w, dx1.view(M, D), dx0.view(M, D),
-                  g_prev, prev_dp2, N, grad_buf(bp.n1w), grad_buf(bp.n1b))
+                  g_prev, prev_dp2, N, grad_buf(bp.n1w), grad_buf(bp.n1b),
+                  gsum=grad_buf(prev_fc2_b) if (g_prev is not None and prev_fc2_b is not None) else None)
     return dx0, g_prev
 
 
@@ -312,6 +314,7 @@ class EncoderFn(torch.autograd.Function):
         if ne and dencs[nb - 1] is not None:
             dx = dx + dencs[nb - 1]
         g = scale_cast(dx, saved[nb - 1]["dp2"], N)
+        g_bias_done = False           # fc2 bias gradient of block i comes fused from block i+1's LN1 backward
         for i in range(nb - 1, -1, -1):
             bp = cfg.blocks[i]
             dq = dqkvs[i] if nq else None
@@ -320,7 +323,10 @@ class EncoderFn(torch.autograd.Function):
             da = datts[i] if na else None
             prev_dp2 = saved[i - 1]["dp2"] if i > 0 else None
             extra = dencs[i - 1] if (ne and i > 0 and dencs[i - 1] is not None) else None
-            dx, g = _block_backward(dx, g, saved[i], bp, cfg, dq, da, prev_dp2, want_prev_g=(i > 0 and extra is None))
+            fuse_prev = i > 0 and extra is None
+            dx, g = _block_backward(dx, g, saved[i], bp, cfg, dq, da, prev_dp2, want_prev_g=fuse_prev,
+                                    prev_fc2_b=cfg.blocks[i - 1].fc2_b if fuse_prev else None, g2_bias_done=g_bias_done)
+            g_bias_done = fuse_prev
             if extra is not None:
                 dx = dx + extra
                 g = scale_cast(dx, prev_dp2, N)

@@ -51,6 +51,8 @@ int devit_check_device(int dev);
  *   [B,198,D] gradient.
  *   batch > 1: operand z uses ptr + z * batch_stride (elements); output uses out + z * out_batch_stride.
  *   Requirements: M % 128 == 0, N % 128 == 0, K % 64 == 0, 16-byte aligned pointers / strides.
+ *   Instantiated (layout, epilogue) pairs: A,B k-contiguous: STORE_BF16/F32, GELU, RESIDUAL, PATCH; B k-major
+ *   (dgrad): STORE_BF16/F32, DGELU; A and B k-major (wgrad): ATOMIC_F32, STORE_F32.  Others: DEVIT_ERR_ARG.
  *   split_k > 1 is only legal with DEVIT_EPI_ATOMIC_F32.  ep->m_valid > 0 stores only rows m < m_valid
  *   of each batch (padded per-image Grams of the relation loss).
  * ---------------------------------------------------------------------------------------- */
@@ -83,7 +85,7 @@ typedef struct {
   const float* pos;        /* PATCH: [tok + T][N] f32 position embedding */
   int patch_tokens;        /* PATCH: T = 196 */
   int extra_tokens;        /* PATCH: tok = 2 (cls + dist) or 1 */
-  int exact_gelu;          /* 1 = erff() (parity mode), 0 = 1.5e-7-accurate fast erf */
+  int exact_gelu;          /* must be 0: GELU uses an erf with |err| < 1.5e-7 (erff() variant not built) */
   long long out_batch_stride; /* elements between consecutive batch outputs (out, aux, aux_in, res) */
   int m_valid;             /* > 0: rows m >= m_valid of each batch are not stored */
 } devit_epilogue;
@@ -108,7 +110,9 @@ int devit_gemm_bf16(const devit_operand* A, const devit_operand* B, int M, int N
  *   D % 128 == 0, D <= 1024.
  * bwd: dx[phys row] = (dres ? dres[phys row] : 0) + LN'(dy[r]); dx_bf16 (optional) = rowscale * dx as the
  *   bf16 branch gradient consumed by the previous sub-block's dgrad / wgrad GEMMs;
- *   dgamma / dbeta [D] (accumulate != 0 adds).  workspace >= devit_layernorm_bwd_workspace(rows, D).
+ *   dgamma / dbeta [D] (accumulate != 0 adds); dx_bf16_colsum (optional) [D] (+)= column sums of dx_bf16 = the
+ *   bias gradient of the Linear layer that produced the branch (saves a pass over the matrix).
+ *   workspace >= devit_layernorm_bwd_workspace(rows, D).
  * ---------------------------------------------------------------------------------------- */
 int devit_layernorm_fwd(const float* x, int rows, int D, int in_group, int in_stride, const float* gamma,
                         const float* beta, float eps, void* y_bf16, float* y_f32, float* mean, float* rstd,
@@ -117,7 +121,7 @@ size_t devit_layernorm_bwd_workspace(int rows, int D);
 int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows, int D, int in_group, int in_stride,
                         const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
                         void* dx_bf16, const float* rowscale, int rows_per_scale, float* dgamma, float* dbeta,
-                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                        float* dx_bf16_colsum, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused attention core.  Replaces models/de_vit.py:68-79 (unbind q,k,v; q k^T * scale; softmax;

@@ -9,13 +9,13 @@ L.LIB_PATH = os.path.join(ROOT, "tools", "_diag", "libdevit_hip_stamps.so")
 from devit_amd import ops
 lib = L.load()
 dev = torch.device("cuda")
-def run(M, N, K, a_km, b_km, kind, label):
+def run(M, N, K, a_km, b_km, kind, label, m_valid=0):
     a = torch.randn((K, M) if a_km else (M, K), device=dev).to(torch.bfloat16)
     b = (torch.randn((K, N) if b_km else (N, K), device=dev) * 0.02).to(torch.bfloat16)
     out = torch.zeros((M, N), dtype=torch.float32 if kind in (5, 6) else torch.bfloat16, device=dev)
     buf = (C.c_ulonglong * 8)()
     for i in range(3):
-        ops.gemm(a, a.stride(0), a_km, b, b.stride(0), b_km, M, N, K, kind=kind, out=out, ldc=N, split_k=(16 if kind == 5 else 1))
+        ops.gemm(a, a.stride(0), a_km, b, b.stride(0), b_km, M, N, K, kind=kind, out=out, ldc=N, split_k=(16 if kind == 5 else 1), m_valid=m_valid)
         torch.cuda.synchronize()
         lib.devit_debug_gemm_stamps(buf, 1)
     tot = sum(buf[:4])
@@ -34,3 +34,7 @@ run(8192, 2048, 512, 0, 0, 0, "L2 NT 8192x2048x512")
 run(8192, 2048, 512, 0, 1, 0, "L2 A_row/B_km")
 run(8192, 2048, 512, 1, 1, 6, "L2 A_km/B_km")
 run(8192, 2048, 4096, 0, 0, 0, "NT 8192x2048x4096")
+print("--- T qkv without output stores (m_valid = 1)")
+run(50688, 2304, 768, 0, 0, 0, "T qkv NT, no stores", m_valid=1)
+run(50688, 2304, 3072, 0, 0, 0, "50688x2304x3072 NT")
+run(50688, 2304, 3072, 0, 0, 0, "50688x2304x3072 NT no st", m_valid=1)
