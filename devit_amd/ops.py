@@ -87,9 +87,14 @@ def _profiled_gemm(kw):
         PROFILE = rec
 
 
-def split_k_for(out_rows, out_cols, ksteps, target_wgs=512):
-    tiles = (out_rows // 128) * (out_cols // 128)
-    return max(1, min(ksteps, (target_wgs + tiles - 1) // tiles))
+def split_k_for(out_rows, out_cols, ksteps):
+    """Split-K factor of a weight-gradient GEMM: fill the 256 CUs without spilling into a nearly empty extra round.
+    Mirrors the tile choice of devit_gemm_bf16 (256-row tiles run one workgroup per CU, 128x128 tiles two)."""
+    bm = 256 if out_rows % 256 == 0 else 128
+    bn = 256 if (bm == 256 and out_cols % 256 == 0) else 128
+    tiles = (out_rows // bm) * (out_cols // bn)
+    slots = 256 * (2 if bm == 128 else 1) * 2          # two rounds of resident workgroups
+    return max(1, min(ksteps, slots // tiles))
 
 
 def linear_fwd(x, w, bias, M, *, out, kind=L.EPI_STORE_BF16, **kw):

@@ -44,6 +44,16 @@ class FlatAdamW:
              ptr(self.gnorm_sq) if clip else None, ptr(self._dyn), f.numel, b1, b2, self.eps, self.weight_decay,
              float(self.max_norm or 0.0), float(self.ema_decay or 0.0), 1.0, stream_ptr())
 
+    def ema_state_dict(self, model):
+        """EMA weights keyed like model.state_dict() (timm get_state_dict(model_ema), distill_sub.py:429)."""
+        if self.ema is None:
+            return None
+        f, out = self.flat, {}
+        by_id = {id(p): n for n, p in model.named_parameters()}
+        for p, o in zip(f.params, f.offsets):
+            out[by_id[id(p)]] = self.ema[o:o + p.numel()].view_as(p).clone()
+        return {k: out[k] for k in model.state_dict() if k in out}
+
     def state_dict(self):
         return {"m": self.m, "v": self.v, "ema": self.ema, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
 

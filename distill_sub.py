@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""distill_sub.py on MI355X: flag-compatible re-host of the reference's DEKD distillation CLI.
+
+Same flags, defaults, output-directory naming, checkpoint files and per-epoch loop as the reference
+(distill_sub.py:36-205 flags, :247-251 naming, :412-469 loop); the step itself runs on devit_amd
+(HIP kernels + bucketed RCCL gradient exchange + fused AdamW/EMA).  Launch like the reference:
+
+    python -m torch.distributed.run --nproc_per_node=8 distill_sub.py --model dedeit \
+        --teacher-model deit_base_distilled_patch16_224 --teacher-path <dir> --dataset cifar100 --num_division 4 ...
+
+Differences, all host-side: (1) `--synthetic N` trains/evaluates on N on-device random batches per epoch (the image
+has no torchvision / datasets; the JPEG pipeline of data/ is outside the hot path) -- without it a
+dataset provider must be importable as `data.get_dataset.build_division_dataset` (the reference's own module);
+(2) bf16 needs no loss scaling: `scaler` in checkpoints is an empty dict; (3) Mixup/CutMix run as device-side
+tensor ops (SURVEY §8f-4 "next").
+"""
+import argparse
+import datetime
+import json
+import math
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+import devit_amd
+from devit_amd import ddp, engine, losses, optim, utils
+from devit_amd.de_vit import model_config
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser('DeViT sub-model distillation (MI355X)', add_help=False)
+    a = p.add_argument
+    a('--batch-size', default=2, type=int); a('--eval-batch-size', default=512, type=int); a('--epochs', default=5, type=int)
+    a('--output_dir', default=r'./output'); a('--finetune', action='store_true')
+    a('--model', default='dedeit', type=str, metavar='MODEL'); a('--model-path', type=str, default='')
+    a('--input-size', default=224, type=int); a('--drop', type=float, default=0.0); a('--drop-path', type=float, default=0.1)
+    a('--model-ema', action='store_true'); a('--no-model-ema', action='store_false', dest='model_ema'); p.set_defaults(model_ema=True)
+    a('--model-ema-decay', type=float, default=0.99996); a('--model-ema-force-cpu', action='store_true', default=False)
+    a('--opt', default='adamw', type=str); a('--opt-eps', default=1e-8, type=float); a('--opt-betas', default=None, type=float, nargs='+')
+    a('--clip-grad', type=float, default=1.0); a('--momentum', type=float, default=0.9); a('--weight-decay', type=float, default=0)
+    a('--sched', default='cosine', type=str); a('--lr', type=float, default=5e-4)
+    a('--lr-noise', type=float, nargs='+', default=None); a('--lr-noise-pct', type=float, default=0.67); a('--lr-noise-std', type=float, default=1.0)
+    a('--warmup-lr', type=float, default=1e-6); a('--min-lr', type=float, default=1e-5); a('--decay-epochs', type=float, default=30)
+    a('--warmup-epochs', type=int, default=5); a('--cooldown-epochs', type=int, default=10); a('--patience-epochs', type=int, default=10)
+    a('--decay-rate', '--dr', type=float, default=0.1)
+    a('--color-jitter', type=float, default=0.4); a('--aa', type=str, default='rand-m9-mstd0.5-inc1'); a('--smoothing', type=float, default=0.1)
+    a('--train-interpolation', type=str, default='bicubic'); a('--repeated-aug', action='store_true')
+    a('--no-repeated-aug', action='store_false', dest='repeated_aug'); p.set_defaults(repeated_aug=True); a('--no_aug', action='store_true')
+    a('--reprob', type=float, default=0.25); a('--remode', type=str, default='pixel'); a('--recount', type=int, default=1)
+    a('--resplit', action='store_true', default=False)
+    a('--mixup', type=float, default=0.8); a('--cutmix', type=float, default=1.0); a('--cutmix-minmax', type=float, nargs='+', default=None)
+    a('--mixup-prob', type=float, default=1.0); a('--mixup-switch-prob', type=float, default=0.5); a('--mixup-mode', type=str, default='batch')
+    a('--teacher-model', default='vit_large_patch16_224', type=str); a('--teacher-path', type=str, default='')
+    a('--distillation-type', default='hard', choices=['none', 'soft', 'hard'], type=str)
+    a('--distillation-inter', type=bool, default=True); a('--distillation-token', action='store_true')
+    a('--distillation-alpha', default=0.5, type=float); a('--distillation-tau', default=1.0, type=float)
+    a('--gama', nargs='+', default=[0.2, 0.1, 0.3])
+    a('--data-path', default=r'./datasets'); a('--dataset', default='cifar100', choices=['cifar100', 'IMNET', 'cars', 'pets', 'flowers'])
+    a('--inat-category', default='name'); a('--num_division', metavar='N', type=int, default=4); a('--start-division', metavar='N', type=int, default=0)
+    a('--device', default='cuda'); a('--seed', default=0, type=int); a('--resume', default=''); a('--start_epoch', default=0, type=int)
+    a('--eval', action='store_true'); a('--dist-eval', action='store_true', default=False); a('--num_workers', default=4, type=int)
+    a('--local_rank', type=int, default=-1); a('--pin-mem', action='store_true'); a('--no-pin-mem', action='store_false', dest='pin_mem')
+    p.set_defaults(pin_mem=True); a('--world_size', default=1, type=int); a('--dist_url', default='env://')
+    a('--load_shrink', action='store_true', default=False); a('--shrink_checkpoint', type=str, default='')
+    a('--neuron_shrinking', action='store_true', default=False); a('--head_shrinking', action='store_true', default=False)
+    a('--synthetic', type=int, default=0, metavar='STEPS', help='train on STEPS random on-device batches per epoch')
+    return p
+
+
+NUM_CLASSES = {'cifar100': 100, 'IMNET': 1000, 'cars': 196, 'pets': 37, 'flowers': 102}
+
+
+class SyntheticLoader:
+    """`steps` resident batches; same (images fp32 [B,3,224,224], labels int64 [B]) contract as the DataLoader."""
+
+    def __init__(self, steps, batch, classes, device, seed):
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.img = torch.randn((batch, 3, 224, 224), generator=g, device=device)
+        self.lab = torch.randint(0, classes, (batch,), generator=g, device=device)
+        self.steps = steps
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            yield self.img, self.lab
+
+
+class Mixup:
+    """timm.data.Mixup(mode='batch') semantics as device tensor ops."""
+
+    def __init__(self, mixup_alpha, cutmix_alpha, prob, switch_prob, label_smoothing, num_classes):
+        self.ma, self.ca, self.prob, self.sw, self.eps, self.C = mixup_alpha, cutmix_alpha, prob, switch_prob, label_smoothing, num_classes
+
+    def __call__(self, x, y):
+        assert x.shape[0] % 2 == 0, 'Batch size should be even when using this'
+        lam, cut = 1.0, False
+        if np.random.rand() < self.prob:
+            cut = self.ca > 0 and (self.ma <= 0 or np.random.rand() < self.sw)
+            lam = float(np.random.beta(self.ca, self.ca) if cut else np.random.beta(self.ma, self.ma))
+        if cut:
+            H, W = x.shape[-2:]
+            r = math.sqrt(1 - lam)
+            ch, cw, cy, cx = int(H * r), int(W * r), np.random.randint(H), np.random.randint(W)
+            y0, y1, x0, x1 = max(cy - ch // 2, 0), min(cy + ch // 2, H), max(cx - cw // 2, 0), min(cx + cw // 2, W)
+            x[:, :, y0:y1, x0:x1] = x.flip(0)[:, :, y0:y1, x0:x1]
+            lam = 1.0 - (y1 - y0) * (x1 - x0) / float(H * W)
+        elif lam != 1.0:
+            x = x * lam + x.flip(0) * (1 - lam)
+        off, on = self.eps / self.C, 1 - self.eps + self.eps / self.C
+        oh = torch.full((y.shape[0], self.C), off, device=x.device).scatter_(1, y[:, None], on)
+        return x, oh * lam + oh.flip(0) * (1 - lam)
+
+
+class CosineEpochs:
+    """timm cosine scheduler as configured by create_scheduler: per-epoch, linear warm-up."""
+
+    def __init__(self, opt, args):
+        self.opt, self.a, self.base, self.last = opt, args, args.lr, -1
+        self._set(0)
+
+    def _set(self, epoch):
+        a = self.a
+        if epoch < a.warmup_epochs:
+            lr = a.warmup_lr + (self.base - a.warmup_lr) * epoch / max(a.warmup_epochs, 1)
+        else:
+            lr = a.min_lr + 0.5 * (self.base - a.min_lr) * (1 + math.cos(math.pi * epoch / max(a.epochs, 1)))
+        self.opt.param_groups[0]['lr'] = lr
+
+    def step(self, epoch):
+        self.last = epoch
+        self._set(epoch + 1)
+
+    def state_dict(self):
+        return {'last': self.last}
+
+    def load_state_dict(self, sd):
+        self.last = sd['last']
+        self._set(self.last + 1)
+
+
+class StepRunner:
+    """Call-compatible stand-in for timm NativeScaler (engine.py:127): backward, join the bucketed all-reduce,
+    clip + AdamW + EMA in the fused optimizer.  bf16: nothing to scale."""
+
+    def __init__(self, reducer):
+        self.reducer = reducer
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
+        loss.backward()
+        self.reducer.finish()
+        optimizer.max_norm = clip_grad
+        optimizer.step()
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, sd):
+        pass
+
+
+def main(args):
+    utils.init_distributed_mode(args)
+    args.method = 'distill_sub'
+    args.name = (f'lr{args.lr}-bs{args.batch_size}-epochs{args.epochs}-grad{args.clip_grad}'
+                 f'-wd{args.weight_decay}-wm{args.warmup_epochs}-gama{args.gama[0]}_{args.gama[1]}_{args.gama[2]}')
+    args.output_dir = os.path.join(args.output_dir, f'{args.dataset}_div{args.num_division}', f'{args.model}', args.method, args.name)
+    Path(args.output_dir).mkdir(parents=True, exist_ok=True)
+    device = torch.device(args.device)
+    seed = args.seed + utils.get_rank()
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    num_classes = NUM_CLASSES[args.dataset] // args.num_division
+    args.num_classes = num_classes
+    if args.synthetic > 0:
+        train_loader = SyntheticLoader(args.synthetic, args.batch_size, num_classes, device, 1234 + utils.get_rank())
+        val_loader = SyntheticLoader(max(1, args.synthetic // 8), args.batch_size, num_classes, device, 99)
+    else:
+        try:
+            from data.get_dataset import build_division_dataset      # the reference's dataset package, if on PYTHONPATH
+        except Exception as e:
+            raise SystemExit("no dataset provider importable (data.get_dataset); use --synthetic N. " + str(e))
+        raise SystemExit("real-data loaders are host-side plumbing outside this build; use --synthetic N")
+
+    mixup_fn = None
+    if args.mixup > 0 or args.cutmix > 0. or args.cutmix_minmax is not None:
+        mixup_fn = Mixup(args.mixup, args.cutmix, args.mixup_prob, args.mixup_switch_prob, args.smoothing, num_classes)
+
+    stu_nb = 1000 if args.model_path != '' else num_classes
+    resize_dim = model_config[args.teacher_model]["embed_dim"] if args.distillation_token else None
+    model = devit_amd.create_model(args.model, pretrained=True, pretrained_path=args.model_path if args.finetune else None,
+                                   num_classes=stu_nb, resize_dim=resize_dim, drop_rate=args.drop,
+                                   drop_path_rate=args.drop_path, drop_block_rate=None)
+    if args.model_path != '':
+        model.reset_classifier(num_classes=num_classes)
+    model.to(device)
+    teacher = None
+    if args.distillation_type != 'none':
+        teacher = devit_amd.create_model(args.teacher_model, num_classes=num_classes, drop_rate=args.drop,
+                                         drop_path_rate=args.drop_path, drop_block_rate=None)
+        tp = os.path.join(args.teacher_path, f'sub-dataset{args.start_division}', 'checkpoint.pth') if args.teacher_path else ''
+        if tp and os.path.exists(tp):
+            teacher.load_state_dict(torch.load(tp, map_location='cpu'))
+        elif not args.synthetic:
+            raise SystemExit(f"teacher checkpoint not found: {tp}")
+        teacher.to(device).eval()
+        for p_ in teacher.parameters():
+            p_.requires_grad_(False)
+
+    flat = ddp.FlatParams(model).attach_bf16(model)
+    ddp.broadcast_parameters(flat)
+    reducer = ddp.BucketedGradReducer(flat).attach(model)
+    args.lr = args.lr * args.batch_size * utils.get_world_size() / 512.0             # distill_sub.py:338
+    optimizer = optim.FlatAdamW(flat, lr=args.lr, eps=args.opt_eps, betas=tuple(args.opt_betas or (0.9, 0.999)),
+                                weight_decay=args.weight_decay, max_norm=args.clip_grad,
+                                ema_decay=args.model_ema_decay if args.model_ema else None)
+    loss_scaler, lr_scheduler = StepRunner(reducer), CosineEpochs(optimizer, args)
+    base = losses.SoftTargetCrossEntropy() if mixup_fn is not None else torch.nn.CrossEntropyLoss()
+    criterion = losses.DistillLoss(base, args.distillation_type, args.distillation_alpha, args.distillation_tau)
+    n_parameters = sum(p_.numel() for p_ in model.parameters() if p_.requires_grad)
+
+    if args.resume:
+        ck = torch.load(args.resume, map_location='cpu')
+        model.load_state_dict(ck['model'])
+        flat.attach_bf16(model)
+        if not args.eval and 'optimizer' in ck:
+            optimizer.load_state_dict(ck['optimizer'])
+            lr_scheduler.load_state_dict(ck['lr_scheduler'])
+            args.start_epoch = ck['epoch'] + 1
+    if args.eval:
+        print(engine.evaluate(val_loader, model, device))
+        return
+
+    output_dir, max_accuracy, start = Path(args.output_dir), 0.0, time.time()
+    for epoch in range(args.start_epoch, args.epochs):
+        train_stats = engine.train_1epoch_qkv(model=model, teacher_model=teacher, criterion=criterion, args=args,
+                                              data_loader=train_loader, optimizer=optimizer, device=device, epoch=epoch,
+                                              loss_scaler=loss_scaler, log=None, max_norm=args.clip_grad, mixup_fn=mixup_fn)
+        lr_scheduler.step(epoch)
+        utils.save_on_master({'model': model.state_dict(), 'optimizer': optimizer.state_dict(),
+                              'lr_scheduler': lr_scheduler.state_dict(), 'epoch': epoch,
+                              'model_ema': optimizer.ema_state_dict(model), 'scaler': loss_scaler.state_dict(),
+                              'args': args}, output_dir / 'checkpoint_temp.pth')
+        test_stats = engine.evaluate(val_loader, model, device)
+        print(f"Epoch: {epoch}/{args.epochs}  [Train] Loss: {train_stats.get('loss', float('nan')):.4f}  "
+              f"[Eval] Top-1: {test_stats['acc1']:.4f} Top-5: {test_stats['acc5']:.4f} Loss: {test_stats['loss']:.4f}")
+        if max_accuracy < test_stats["acc1"]:
+            max_accuracy = test_stats["acc1"]
+            if utils.is_main_process():
+                torch.save(model.state_dict(), output_dir / 'checkpoint.pth')
+                torch.save(args, output_dir / 'training_args.bin')
+                (output_dir / 'result.txt').write_text(f'Final Accuracy: {max_accuracy}\n')
+        if utils.is_main_process():
+            with (output_dir / "log.txt").open("a") as f:
+                f.write(json.dumps({**{f'train_{k}': v for k, v in train_stats.items()},
+                                    **{f'test_{k}': v for k, v in test_stats.items()}, 'epoch': epoch,
+                                    'n_parameters': n_parameters}) + "\n")
+    print(f'Training time {datetime.timedelta(seconds=int(time.time() - start))} on sub-dataset{args.start_division}')
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser('DeViT sub-model distillation (MI355X)', parents=[get_args_parser()])
+    main(parser.parse_args())
