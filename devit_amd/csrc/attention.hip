@@ -42,23 +42,24 @@ __device__ __forceinline__ bf16x8 pbuf_tr_frag(const char* buf, int k0, int c0, 
 
 // Copy rows [0, KROWS) of a strided [N][64] bf16 matrix into an LDS image, zero rows >= N.
 // All 7 loads of a thread are issued before the first LDS write (one HBM latency, not seven).
+template <int NT = 256>
 __device__ __forceinline__ void load_image(char* img, const __bf16* src, size_t row_stride, int N, float mul, int tid) {
-  constexpr int ITERS = KROWS * 8 / 256;
+  constexpr int ITERS = (KROWS * 8 + NT - 1) / NT;
   bf16x8 v[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + it * 256, row = idx >> 3, c = idx & 7;
+    const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     v[it] = row < N ? *(const bf16x8*)(src + (size_t)row * row_stride + c * 8) : z;
   }
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + it * 256, row = idx >> 3, c = idx & 7;
+    const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
     if (mul != 1.0f) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[it][e] = f2bf(bf2f(v[it][e]) * mul);
     }
-    *(bf16x8*)(img + img_off(row, c)) = v[it];
+    if (row < KROWS) *(bf16x8*)(img + img_off(row, c)) = v[it];
   }
 }
 
@@ -85,16 +86,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   const int D = a.H * HD, N = a.N;
   const size_t rs = (size_t)3 * D;
   const __bf16* qbase = a.qkv + (size_t)b * N * rs + h * HD;
-  load_image(k_img, qbase + D, rs, N, 1.0f, tid);
-  load_image(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
-  __syncthreads();
-
   const float c2 = a.scale * 1.4426950408889634f;  // scores in log2 domain
   const float gate = a.head_gate ? a.head_gate[h] : 1.0f;
   const int ntile = (N + 15) >> 4;
   const int g = lane >> 4, lc = lane & 15;
   const int tq = (lane >> 2) & 3, tp = lane & 3;     // transposed-read row / column-quad of this lane
+  load_image(k_img, qbase + D, rs, N, 1.0f, tid);
+  load_image(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
 
+  __syncthreads();
   for (int qt = wave; qt < ntile; qt += 4) {
     const int q = qt * 16 + lc;                      // this lane's query
     bf16x8 qf[2];
@@ -193,7 +193,9 @@ __device__ __forceinline__ void store_grad4(__bf16* dst, const __bf16* add, f32x
   *(bf16x4*)dst = o;
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
+constexpr int BWD_WAVES = 8;
+
+__global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_img = smem;
   char* k_img = smem + IMG_BYTES;
@@ -213,12 +215,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
   const __bf16* dobase = a.dout + (size_t)b * N * D + h * HD;
   const __bf16* obase = a.out + (size_t)b * N * D + h * HD;
 
-  load_image(q_img, qbase, rs, N, 1.0f, tid);
-  load_image(k_img, qbase + D, rs, N, 1.0f, tid);
-  load_image(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
-  load_image(do_img, dobase, (size_t)D, N, gate, tid);
+  load_image<BWD_WAVES * 64>(q_img, qbase, rs, N, 1.0f, tid);
+  load_image<BWD_WAVES * 64>(k_img, qbase + D, rs, N, 1.0f, tid);
+  load_image<BWD_WAVES * 64>(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
+  load_image<BWD_WAVES * 64>(do_img, dobase, (size_t)D, N, gate, tid);
   // zero both dS^T buffers once: key rows of tiles that are never written (>= ntile) must read as 0 in dQ
-  for (int i = tid; i < 2 * DST_BYTES / 16; i += 256) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 2 * DST_BYTES / 16; i += BWD_WAVES * 64) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (tid < KROWS) {
     float l2 = 0.f, dl = 0.f;
     if (tid < N) {
@@ -246,9 +248,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
   const int g = lane >> 4, lc = lane & 15;
   const int tq = (lane >> 2) & 3, tp = lane & 3;
 
-  f32x4 dv[4][4], dk[4][4];    // [key tile of this wave][d tile]: rows d = 4g + r, col key = lc
+  constexpr int KT = (MAXT + BWD_WAVES - 1) / BWD_WAVES;   // key tiles per wave (2)
+  f32x4 dv[KT][4], dk[KT][4];  // [key tile of this wave][d tile]: rows d = 4g + r, col key = lc
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < KT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       dv[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -287,8 +290,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
       }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int kt = wave + t * 4;
+    for (int t = 0; t < KT; ++t) {
+      const int kt = wave + t * BWD_WAVES;
       if (kt < ntile) {
         bf16x8 kf[2], vf[2];
 #pragma unroll
@@ -330,9 +333,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
     }
     __syncthreads();   // dS^T of this block complete (the other buffer is free again two blocks later)
     {
-      // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: wave -> query tile i = wave >> 1, d tiles {2(wave&1), +1}
-      const int i = wave >> 1, dt0 = (wave & 1) * 2;
-      f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: wave -> query tile i = wave >> 2, d tile wave & 3
+      const int i = wave >> 2, dt0 = wave & 3;
+      f32x4 dq[1] = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int ks = 0; ks < 7; ++ks) {
         const int kr = ks * 32 + g * 8 + tq;
@@ -340,12 +343,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
         const char* pb = dst + kr * (DST_STRIDE * 2) + (i * 16 + tp * 4) * 2;
         const bf16x8 bfr = cat8(lds_tr_read(pb), lds_tr_read(pb + 4 * DST_STRIDE * 2));
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dq[u] = mfma16(img_tr_frag(k_img, ks * 32, (dt0 + u) * 16, lane), bfr, dq[u]);
+        for (int u = 0; u < 1; ++u) dq[u] = mfma16(img_tr_frag(k_img, ks * 32, (dt0 + u) * 16, lane), bfr, dq[u]);
       }
       const int q = qb * 32 + i * 16 + lc;
       if (q < N) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 1; ++u) {
           const size_t o = ((size_t)b * N + q) * rs + h * HD + (dt0 + u) * 16 + g * 4;
           store_grad4(a.dqkv + o, a.dqkv_add ? a.dqkv_add + o : nullptr, dq[u]);
         }
@@ -354,8 +357,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
   }
   // ---- dK, dV of this wave's key tiles: lane = key, 4 consecutive d per register quad
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int kt = wave + t * 4, key = kt * 16 + lc;
+  for (int t = 0; t < KT; ++t) {
+    const int kt = wave + t * BWD_WAVES, key = kt * 16 + lc;
     if (kt < ntile && key < N) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -403,7 +406,7 @@ extern "C" int devit_attn_bwd(const void* qkv, const void* out, const void* dout
   }
   AttnBwdArgs a{(const __bf16*)qkv, (const __bf16*)out, (const __bf16*)dout, lse, head_gate,
                 (const __bf16*)dqkv_add, (__bf16*)dqkv, B, N, H, scale};
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), BWD_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(BWD_WAVES * 64), BWD_LDS, (hipStream_t)stream, a);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }

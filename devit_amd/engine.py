@@ -7,6 +7,7 @@ The five `.item()` host syncs + `cuda.synchronize()` per step of the reference (
 kept for logging parity in train_1epoch_qkv, but only every `print_freq` steps.
 """
 import math
+import os
 import sys
 
 import torch
@@ -18,13 +19,15 @@ def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3)
                     criterion=None, dp_scales="draw"):
     """One DEKD forward.  Returns dict(loss, cls_loss, q_loss, k_loss, v_loss, logits, teacher_logits)."""
     vit = model.module if hasattr(model, "module") else model
+    pre_teacher = None
+    if os.environ.get("DEVIT_TEACHER_STREAM", "1") == "1" and samples.is_cuda:
+        pre_teacher = _teacher_forward_async(teacher_model, samples)
     if dp_scales != "draw":   # explicit DropPath masks (parity tests)
         outputs = _forward_with_dp(vit, samples, dp_scales)
     else:
         outputs = model(samples, output_qkv=True)                                   # engine.py:70
     logits, qkvs = outputs['output'], outputs['qkv']
-    with torch.no_grad():
-        teacher_outputs = teacher_model(samples, output_qkv=True)                   # engine.py:73-76
+    teacher_outputs = pre_teacher() if pre_teacher is not None else _teacher_forward(teacher_model, samples)  # engine.py:73-76
     teacher_logits, teacher_qkvs = teacher_outputs['output'], teacher_outputs['qkv']
     if criterion is None:
         criterion = losses.DistillLoss(losses.SoftTargetCrossEntropy(), kind, alpha, tau)
@@ -36,6 +39,45 @@ def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3)
     loss = cls_loss + float(gama[0]) * q_loss + float(gama[1]) * k_loss + float(gama[2]) * v_loss   # :105-106
     return dict(loss=loss, cls_loss=cls_loss, q_loss=q_loss, k_loss=k_loss, v_loss=v_loss, logits=logits,
                 teacher_logits=teacher_logits)
+
+
+_side_stream = {}
+
+
+def _teacher_forward(teacher_model, samples):
+    """Frozen teacher forward.  With DEVIT_TEACHER_STREAM=1 it is enqueued on a side stream before the student
+    forward has drained, so the tail rounds of one model's GEMMs are filled by the other's workgroups."""
+    if os.environ.get("DEVIT_TEACHER_STREAM", "1") != "1" or not samples.is_cuda:
+        with torch.no_grad():
+            return teacher_model(samples, output_qkv=True)
+    main = torch.cuda.current_stream()
+    side = _side_stream.setdefault(samples.device.index, torch.cuda.Stream())
+    side.wait_stream(main)          # NOTE: call this BEFORE the student forward is enqueued to get overlap
+    with torch.cuda.stream(side), torch.no_grad():
+        out = teacher_model(samples, output_qkv=True)
+    main.wait_stream(side)
+    out['output'].record_stream(main)
+    for qkv in out['qkv']:
+        q = qkv[0]
+        getattr(q, "_devit_packed", (q,))[0].record_stream(main)
+    return out
+
+
+def _teacher_forward_async(teacher_model, samples):
+    """Enqueue the teacher forward on the side stream now; the returned callable joins it."""
+    main = torch.cuda.current_stream()
+    side = _side_stream.setdefault(samples.device.index, torch.cuda.Stream())
+    side.wait_stream(main)
+    with torch.cuda.stream(side), torch.no_grad():
+        out = teacher_model(samples, output_qkv=True)
+
+    def join():
+        main.wait_stream(side)
+        out['output'].record_stream(main)
+        for qkv in out['qkv']:
+            getattr(qkv[0], "_devit_packed", (qkv[0],))[0].record_stream(main)
+        return out
+    return join
 
 
 def _forward_with_dp(vit, samples, dp_scales):
