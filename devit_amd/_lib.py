@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdevit_hip.so")
+LIB_PATH = os.environ.get("DEVIT_LIB_PATH") or os.path.join(_HERE, "libdevit_hip.so")   # override: diagnostics only
 
 # devit_epilogue_kind
 EPI_STORE_BF16, EPI_GELU_BF16, EPI_RESIDUAL_F32, EPI_PATCH_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_STORE_F32 = range(7)

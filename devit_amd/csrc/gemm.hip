@@ -275,7 +275,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
     STAMP(s1);
     __builtin_amdgcn_s_barrier();  // everyone's stage-t DMA landed; everyone finished reading stage t-1
     STAMP(s2);
+#ifndef DEVIT_GEMM_DMA_MID
     if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1);  // overwrites the buffer read at step t-1
+#endif
     STAMP(s3);
     const char* cur = smem + (t % NSTAGE) * STAGE_BYTES;
 #ifdef DEVIT_GEMM_NOCOMPUTE
@@ -283,6 +285,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
 #endif
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+#ifdef DEVIT_GEMM_DMA_MID
+      if (kk == 1) {   // issue the refill between the two MFMA bursts: the SIMD's other wave is usually mid-burst
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       bf16x8 af[MI], bfr[NI];
 #pragma unroll
       for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN>(cur + A_TILE_BYTES, wn * WN + j * 16, kk, lane);
