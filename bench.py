@@ -151,6 +151,9 @@ def main():
     img_per_s = B * world * args.steps / dt
 
     # ---- dominant-kernel roofline: one extra instrumented step, events on the launch stream ------------------
+    os.environ["DEVIT_TEACHER_STREAM"] = "0"      # serialise the two forwards so that event brackets time ONE kernel
+    step()
+    torch.cuda.synchronize()
     ops.PROFILE = []
     step()
     torch.cuda.synchronize()
@@ -163,7 +166,7 @@ def main():
         d[2] += 1
     dom = "A_row/B_row"
     fl, tm, cnt = by_t[dom]
-    roof = {"bound": "mfma", "kernel": "gemm_kernel<A_row,B_row> (128x128x64 bf16 MFMA, fwd Linear layers)",
+    roof = {"bound": "mfma", "kernel": "gemm_kernel<*, A_row, B_row, *> (256x256 / 256x128 x64 bf16 MFMA tiles; fwd Linear layers of teacher + student)",
             "achieved": round(fl / tm / 1e12, 2), "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
             "frac": round(fl / tm / BF16_DENSE_PEAK, 4), "traffic": None,
             "launches_per_step": cnt, "avg_launch_us": round(tm / cnt * 1e6, 2),

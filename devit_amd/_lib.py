@@ -58,7 +58,14 @@ SIGNATURES = {
     "devit_adamw_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _F, _P]),
     "devit_cls_distill_loss": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "devit_relation_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "devit_relation_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "devit_relation_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "devit_gemm_f32": (_I, [_P, _LL, _LL, _LL, _LL, _P, _LL, _LL, _LL, _LL, _I, _I, _I, _I, _I, _LL, _LL, _I, _I, _F, _P, _I,
+                            C.POINTER(Epilogue), _P]),
+    "devit_softmax_rows_f32": (_I, [_P, _I, _I, _I, _F, _P, _P]),
+    "devit_softmax_bwd_rows_f32": (_I, [_P, _P, _I, _I, _I, _F, _P]),
+    "devit_im2row_f32": (_I, [_P, _P, _I, _P]),
+    "devit_scale_rows_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "devit_colsum_f32": (_I, [_P, _I, _I, _I, _P, _I, _P]),
 }
 
 _lib = None

@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void rel_reduce_kernel(const float* row_kl, in
 struct RelGradArgs {
   const float* rt; const float* rs; const float* lse_t; const float* lse_s;
   const float* upstream;  // device scalar (dL/dloss) or NULL (= 1)
-  __bf16* S;
-  int B, N, ldr;
+  void* S;
+  int B, N, ldr, out_f32;
   float inv_sqrt_t, inv_sqrt_s, coef;  // coef = 1 / (B * sqrt(hd_s))
 };
 __global__ __launch_bounds__(256) void rel_grad_kernel(const RelGradArgs a) {
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void rel_grad_kernel(const RelGradArgs a) {
     const float lti = a.lse_t[b * a.N + i], ltj = a.lse_t[b * a.N + j];
     v = (expf(rs - lsi) + expf(rs - lsj) - expf(rt - lti) - expf(rt - ltj)) * up;
   }
-  a.S[o] = f2bf(v);
+  if (a.out_f32) ((float*)a.S)[o] = v;
+  else ((__bf16*)a.S)[o] = f2bf(v);
 }
 
 }  // namespace
@@ -260,10 +261,10 @@ extern "C" int devit_relation_stats(const float* gram_t, const float* gram_s, in
 
 extern "C" int devit_relation_grad(const float* gram_t, const float* gram_s, const float* lse_t, const float* lse_s,
                                    const float* upstream, int B, int N, int ldr, int head_dim_t, int head_dim_s,
-                                   void* S_bf16, void* stream) {
-  DEVIT_CHECK(gram_t && gram_s && lse_t && lse_s && S_bf16, DEVIT_ERR_ARG, "devit_relation_grad: null pointer");
+                                   void* S_out, int out_is_f32, void* stream) {
+  DEVIT_CHECK(gram_t && gram_s && lse_t && lse_s && S_out, DEVIT_ERR_ARG, "devit_relation_grad: null pointer");
   DEVIT_CHECK(ldr == 256 && N <= 256, DEVIT_ERR_SHAPE, "devit_relation_grad: padded Gram must be 256 wide");
-  RelGradArgs a{gram_t, gram_s, lse_t, lse_s, upstream, (__bf16*)S_bf16, B, N, ldr,
+  RelGradArgs a{gram_t, gram_s, lse_t, lse_s, upstream, S_out, B, N, ldr, out_is_f32,
                 1.0f / sqrtf((float)head_dim_t), 1.0f / sqrtf((float)head_dim_s),
                 1.0f / ((float)B * sqrtf((float)head_dim_s))};
   hipLaunchKernelGGL(rel_grad_kernel, dim3(ldr, B), dim3(256), 0, (hipStream_t)stream, a);

@@ -138,7 +138,7 @@ class Block(nn.Module):
         bp.n2w, bp.n2b = self.norm2.weight, self.norm2.bias
         bp.fc1_w, bp.fc1_b = self.mlp.fc1.weight, self.mlp.fc1.bias
         bp.fc2_w, bp.fc2_b = self.mlp.fc2.weight, self.mlp.fc2.bias
-        bp.qkv_w16, bp.proj_w16 = _w16(self.attn.qkv), _w16(self.attn.proj)
+        bp.qkv_w16, bp.proj_w16 = _w16(self.attn.qkv), _w16(self.attn.proj)     # (unused by the fp32 parity path)
         bp.fc1_w16, bp.fc2_w16 = _w16(self.mlp.fc1), _w16(self.mlp.fc2)
         bp.num_heads = self.attn.num_heads
         bp.head_gate, bp.neuron_gate = self.attn.gate_on(device), self.mlp.gate_on(device)
@@ -182,7 +182,8 @@ def draw_dp_scales(blocks_params, B, device, training):
     return scales if any_dp else None
 
 
-def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=None, dp_scales="draw", exact_gelu=0):
+def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=None, dp_scales="draw", exact_gelu=0,
+               precision="bf16"):
     """Run a list of Blocks as one EncoderFn node.  Returns (x, qkv tuples, att tensors, enc tensors)."""
     L.require_device(x)
     if x.dtype != torch.float32:
@@ -195,7 +196,11 @@ def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=Non
                          grad_ready=grad_ready)
     cfg.grad_enabled = torch.is_grad_enabled()
     flat = [p for bp in bps for p in bp.all_params()]
-    outs = ops.EncoderFn.apply(x, cfg, *flat)
+    if precision == "f32":
+        from . import ops_f32
+        outs = ops_f32.EncoderF32Fn.apply(x, cfg, *flat)
+    else:
+        outs = ops.EncoderFn.apply(x, cfg, *flat)
     nb = len(blocks)
     i = 1
     qkvs = atts = encs = None
@@ -285,6 +290,7 @@ class VisionTransformer(nn.Module):
             self.resize_encoder_mlp = nn.Linear(self.embed_dim, self.resize_dim)
         self.grad_ready = None      # set by devit_amd.ddp.BucketedGradReducer
         self.exact_gelu = 0
+        self.precision = "bf16"     # "f32": exact-fp32 parity path (ops_f32.py), not tuned
         self.init_weights(weight_init)
 
     # ---- init / bookkeeping identical to the reference (de_vit.py:205-240) ------------------------------
@@ -319,6 +325,10 @@ class VisionTransformer(nn.Module):
     def embed(self, x):
         """patch_embed + cls/dist tokens + pos_embed (de_vit.py:258-264) -> fp32 [B, T, D]."""
         L.require_device(x)
+        if self.precision == "f32":
+            from . import ops_f32
+            return ops_f32.PatchEmbedF32Fn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias,
+                                                 self.cls_token, self.dist_token, self.pos_embed, self.grad_ready)
         return ops.PatchEmbedFn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token,
                                       self.dist_token, self.pos_embed, _w16(self.patch_embed.proj), self.grad_ready)
 
@@ -340,7 +350,8 @@ class VisionTransformer(nn.Module):
         x = self.embed(x)
         emb = x
         xo, qkvs, atts, encs = run_blocks(list(self.blocks), x, self.training, output_qkv, output_att, output_encoders,
-                                          grad_ready=self.grad_ready, exact_gelu=self.exact_gelu)
+                                          grad_ready=self.grad_ready, exact_gelu=self.exact_gelu,
+                                          precision=self.precision)
         depth = len(self.blocks)
         encoder_outputs = [emb] if output_emb else []
         encoder_outputs += encs if output_encoders else [None] * depth

@@ -83,7 +83,7 @@ def _teacher_forward_async(teacher_model, samples):
 def _forward_with_dp(vit, samples, dp_scales):
     x = vit.embed(samples)
     xo, qkvs, _, _ = de_vit.run_blocks(list(vit.blocks), x, vit.training, True, False, False,
-                                       grad_ready=vit.grad_ready, dp_scales=dp_scales)
+                                       grad_ready=vit.grad_ready, dp_scales=dp_scales, precision=vit.precision)
     heads = vit._tokens_and_logits(xo, True)
     return {'output': (heads[1], heads[2]) if vit.training else (heads[1] + heads[2]) / 2, 'qkv': qkvs}
 

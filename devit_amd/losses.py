@@ -59,6 +59,10 @@ def relation_losses_packed(student_qkv, teacher_qkv):
     (s_buf, B, N, Hs), (t_buf, Bt, Nt, Ht) = sp, tp
     assert (B, N) == (Bt, Nt)
     hd_s, hd_t = s_buf.shape[1] // (3 * Hs), t_buf.shape[1] // (3 * Ht)
+    if s_buf.dtype == torch.float32:          # exact-fp32 parity path
+        from . import ops_f32
+        losses = ops_f32.RelationLossF32Fn.apply(s_buf, t_buf.detach().float(), B, N, hd_s, hd_t)
+        return losses[0], losses[1], losses[2]
     losses = ops.RelationLossFn.apply(s_buf, t_buf.detach(), B, N, hd_s, hd_t)
     return losses[0], losses[1], losses[2]
 

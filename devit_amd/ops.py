@@ -601,7 +601,7 @@ class RelationLossFn(torch.autograd.Function):
             gt, gs = ctx.grams[j]
             lse_t, lse_s = ctx.stats[j]
             call("devit_relation_grad", ptr(gt), ptr(gs), ptr(lse_t), ptr(lse_s), ptr(g[j:]), B, N, 256, hd_t, hd_s,
-                 ptr(S), stream_ptr())
+                 ptr(S), 0, stream_ptr())
             f = s_qkv[:, j * Ds:]
             # dF[b] (rows < N) = S[b] @ F[b]   (F read k-major; rows >= N of S are zero)
             gemm(S, 256, 0, f, 3 * Ds, 1, 256, Ds, 256, kind=L.EPI_STORE_BF16, out=d[:, j * Ds:], ldc=3 * Ds, batch=B,

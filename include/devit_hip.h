@@ -205,8 +205,31 @@ int devit_cls_distill_loss(const float* logits, const float* logits_kd, const fl
 int devit_relation_stats(const float* gram_t, const float* gram_s, int B, int N, int ldr, int head_dim_t,
                          int head_dim_s, float* lse_t, float* lse_s, float* row_kl, float* loss, void* stream);
 int devit_relation_grad(const float* gram_t, const float* gram_s, const float* lse_t, const float* lse_s,
-                        const float* upstream, int B, int N, int ldr, int head_dim_t, int head_dim_s, void* S_bf16,
-                        void* stream);
+                        const float* upstream, int B, int N, int ldr, int head_dim_t, int head_dim_s, void* S_out,
+                        int out_is_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Exact-fp32 companion path ("parity mode", csrc/sgemm.hip): the same op sequences with fp32 activations and
+ * k-ordered fmaf accumulation, for asserting BASELINE.json's 1e-3 logit bar against the reference's fp32 CPU
+ * path.  Not tuned (a few TFLOP/s); never used by bench.py.
+ *   devit_gemm_f32: C[z][m][n] = alpha * (batch_scale ? batch_scale[z % batch_inner] : 1) *
+ *                                sum_k A[z][m*sam + pk(k)*sak] * B[z][n*sbn + k*sbk]  (+ epilogue, fp32 flavours of
+ *     STORE_F32 / GELU / DGELU / RESIDUAL / PATCH; accumulate != 0 adds into out for STORE_F32)
+ *     batch z = zo * batch_inner + zi uses ptr + zo * bs_outer + zi * bs_inner (image / head);
+ *     pk(k) = k_group > 0 ? k + k_skip * (k / k_group + 1) : k   (A only; patch-embed wgrad)
+ *   devit_softmax_rows_f32 / devit_softmax_bwd_rows_f32: in-place row softmax of scale*S (+ natural-log LSE) and
+ *     its backward dS = scale * P * (dP - sum_j P dP): with the GEMM above they restate de_vit.py:70-74.
+ * ---------------------------------------------------------------------------------------- */
+int devit_gemm_f32(const float* A, long long sam, long long sak, long long a_bs_outer, long long a_bs_inner,
+                   const float* B, long long sbn, long long sbk, long long b_bs_outer, long long b_bs_inner, int M, int N,
+                   int K, int batch, int batch_inner, long long c_bs_outer, long long c_bs_inner, int k_group, int k_skip,
+                   float alpha, const float* batch_scale, int accumulate, const devit_epilogue* ep, void* stream);
+int devit_softmax_rows_f32(float* S, int rows, int ncols, int ld, float scale, float* lse, void* stream);
+int devit_softmax_bwd_rows_f32(const float* P, float* dP, int rows, int ncols, int ld, float scale, void* stream);
+int devit_im2row_f32(const float* img, float* rows, int B, void* stream);
+int devit_scale_rows_f32(const float* src, float* dst, const float* rowscale, int rows_per_scale, int M, int D,
+                         void* stream);
+int devit_colsum_f32(const float* y, int M, int N, int ld, float* out, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }
