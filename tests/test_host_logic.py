@@ -58,8 +58,8 @@ def test_gate_contract_and_drop_path_schedule():
 
 def test_row_padding_and_splitk():
     assert ops.pad_rows(50688) == 50688 and ops.pad_rows(396) == 512 and ops.pad_rows(1) == 256
-    assert ops.split_k_for(1536, 384, 792) == 28        # 18 tiles of 256x128 -> 504 workgroups (2 rounds of 256 CUs)
-    assert ops.split_k_for(1152, 384, 792) == 37        # 27 tiles of 128x128, two resident per CU
+    assert ops.split_k_for(1536, 384, 792) == 14        # 18 tiles of 256x128 -> 252 workgroups (one per CU)
+    assert ops.split_k_for(1152, 384, 792) == 18        # 27 tiles of 128x128, two resident per CU -> 486
     assert 1 <= ops.split_k_for(384, 384, 792) <= 792
     t = ops.rows_alloc(5, 8, torch.float32, torch.device("cpu"))
     assert t.shape == (256, 8) and bool((t[5:] == 0).all())

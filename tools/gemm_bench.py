@@ -40,9 +40,12 @@ for tag, D in (("S", 384), ("T", 768)):
         report("S fc1 dgrad store     N=384 K=1536", 2.0 * M * 4 * D * D, timeit(lambda: ops.gemm(xh, 4 * D, 0, w1, D, 1, M, D, 4 * D, kind=L.EPI_STORE_BF16, out=od, ldc=D)))
         report("S qkv dgrad store     N=384 K=1152", 2.0 * M * 3 * D * D, timeit(lambda: ops.gemm(o3, 3 * D, 0, wqkv, D, 1, M, D, 3 * D, kind=L.EPI_STORE_BF16, out=od, ldc=D)))
         gw = torch.zeros(4 * D, D, device=dev)
-        for sk in (8, 16, 22, 32):
+        for sk in (7, 14, 28):
             report(f"S fc1 wgrad split_k={sk:2d}  [1536,384]", 2.0 * M * 4 * D * D, timeit(lambda: ops.gemm(xh, 4 * D, 1, x, D, 1, 4 * D, D, M, kind=L.EPI_ATOMIC_F32, out=gw, ldc=D, split_k=sk)))
         gq = torch.zeros(D, D, device=dev)
-        for sk in (16, 32, 57):
-            report(f"S proj wgrad split_k={sk:2d} [384,384]", 2.0 * M * D * D, timeit(lambda: ops.gemm(x, D, 1, x, D, 1, D, D, M, kind=L.EPI_ATOMIC_F32, out=gq, ldc=D, split_k=sk)))
+        for sk in (28, 56, 113):
+            report(f"S proj wgrad split_k={sk:3d} [384,384]", 2.0 * M * D * D, timeit(lambda: ops.gemm(x, D, 1, x, D, 1, D, D, M, kind=L.EPI_ATOMIC_F32, out=gq, ldc=D, split_k=sk)))
+        gk = torch.zeros(3 * D, D, device=dev)
+        for sk in (9, 18, 37):
+            report(f"S qkv wgrad split_k={sk:3d} [1152,384]", 2.0 * M * 3 * D * D, timeit(lambda: ops.gemm(o3, 3 * D, 1, x, D, 1, 3 * D, D, M, kind=L.EPI_ATOMIC_F32, out=gk, ldc=D, split_k=sk)))
 json.dump(res, open("gpurun_out/gemm_bench.json", "w"))
