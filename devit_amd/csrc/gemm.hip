@@ -419,8 +419,18 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   g.ep = *ep;
   // tile choice: 256x256 (8 waves of 128x64, 2-deep ring) when both dims allow, else 256x128 (8 waves of
   // 64x64, 3-deep ring), else 128x128 (4 waves)
+  const int variant = (a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0);
   static const int force = getenv("DEVIT_GEMM_TILE") ? atoi(getenv("DEVIT_GEMM_TILE")) : 0;  // 1: 128x128, 2: 256x128
-  int cfg = (M % 256 == 0 && N % 256 == 0) ? 3 : (M % 256 == 0 ? 2 : 1);
+  // Measured on the step's shapes (tools/gemm_tiles.py, M = 50688): 256x256 (one workgroup per CU) wins only when the
+  // K loop is long enough to amortise its un-overlapped prologue/epilogue -- teacher qkv (K 768, plain store) 902 vs
+  // 770 TFLOP/s, fc2 (K 3072) 735 vs 675 -- while 128x128 (two workgroups per CU, one's epilogue under the other's
+  // MFMAs) wins every short-K or epilogue-heavy shape (student qkv 681 vs 624, fc1+GELU 391 vs 369, fc2 558 vs 496,
+  // teacher fc1+GELU 659 vs 629, proj 475 vs 429, fc1 wgrad 640 vs 536).  256x128 won nowhere (kept for experiments).
+  const bool light_epi = ep->kind == DEVIT_EPI_STORE_BF16 || ep->kind == DEVIT_EPI_STORE_F32;
+  int cfg = 1;
+  if (M % 256 == 0 && N % 256 == 0 && (K >= 1536 || (K >= 768 && light_epi)) && variant != 3) cfg = 3;
+  static const int wg_cfg = getenv("DEVIT_GEMM_WGRAD_TILE") ? atoi(getenv("DEVIT_GEMM_WGRAD_TILE")) : 0;
+  if (variant == 3 && wg_cfg > 0) cfg = wg_cfg;
   if (force > 0 && force < cfg) cfg = force;
   const int bm = cfg == 1 ? 128 : 256, bn = cfg == 3 ? 256 : 128;
   g.tiles_m = M / bm;
@@ -429,7 +439,6 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   const long long nwg = (long long)g.tiles_m * g.tiles_n * split_k * batch;
   DEVIT_CHECK(nwg < (1ll << 31), DEVIT_ERR_SHAPE, "devit_gemm_bf16: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  const int variant = (a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0);
 #define DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_)                                          \
   do {                                                                                                         \
     constexpr int ring = NS_ * (BM_ + BN_) * 128, stagebytes = WMM_ * WNN_ * 16384;                            \

@@ -88,13 +88,11 @@ def _profiled_gemm(kw):
 
 
 def split_k_for(out_rows, out_cols, ksteps):
-    """Split-K factor of a weight-gradient GEMM: exactly one round of resident workgroups (256-row tiles run one
-    workgroup per CU, 128x128 tiles two).  More slices only add fp32-atomic traffic (64-128 KB per workgroup at
-    ~1.3 TB/s chip-wide): measured 542 vs 451 TFLOP/s (fc1, 14 vs 28 slices), 596 vs 474 (qkv, 18 vs 37)."""
-    bm = 256 if out_rows % 256 == 0 else 128
-    bn = 256 if (bm == 256 and out_cols % 256 == 0) else 128
-    tiles = (out_rows // bm) * (out_cols // bn)
-    slots = 256 * (2 if bm == 128 else 1)
+    """Split-K factor of a weight-gradient GEMM: exactly one round of resident workgroups (128x128 tiles, two per
+    CU).  More slices only add fp32-atomic traffic (64 KB per workgroup at ~1.3 TB/s chip-wide): measured 640 vs 521
+    TFLOP/s (fc1, 14 vs 28 slices), 590 vs 460 (qkv, 18 vs 37)."""
+    tiles = (out_rows // 128) * (out_cols // 128)     # wgrad always runs 128x128 tiles, two workgroups per CU
+    slots = 512
     return max(1, min(ksteps, slots // tiles))
 
 

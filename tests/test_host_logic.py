@@ -58,7 +58,7 @@ def test_gate_contract_and_drop_path_schedule():
 
 def test_row_padding_and_splitk():
     assert ops.pad_rows(50688) == 50688 and ops.pad_rows(396) == 512 and ops.pad_rows(1) == 256
-    assert ops.split_k_for(1536, 384, 792) == 14        # 18 tiles of 256x128 -> 252 workgroups (one per CU)
+    assert ops.split_k_for(1536, 384, 792) == 14        # 36 tiles of 128x128 -> 504 workgroups (two per CU)
     assert ops.split_k_for(1152, 384, 792) == 18        # 27 tiles of 128x128, two resident per CU -> 486
     assert 1 <= ops.split_k_for(384, 384, 792) <= 792
     t = ops.rows_alloc(5, 8, torch.float32, torch.device("cpu"))
