@@ -76,7 +76,9 @@ struct AttnFwdArgs {
 // registers, so the row softmax is in-lane + two shuffles, and the bf16 P values of two key tiles are already
 // the B operand of O^T = V^T P (k-slot (g, j) = key 16*t(j>>2) + 4g + (j&3); V is read transposed with the
 // same key order).  P never touches LDS; each lane ends up with 4 consecutive d of its own query row.
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
+constexpr int FWD_WAVES = 8;
+
+__global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_img = smem;
   char* v_img = smem + IMG_BYTES;
@@ -91,47 +93,61 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   const int ntile = (N + 15) >> 4;
   const int g = lane >> 4, lc = lane & 15;
   const int tq = (lane >> 2) & 3, tp = lane & 3;     // transposed-read row / column-quad of this lane
-  load_image(k_img, qbase + D, rs, N, 1.0f, tid);
-  load_image(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
-
-  __syncthreads();
-  for (int qt = wave; qt < ntile; qt += 4) {
-    const int q = qt * 16 + lc;                      // this lane's query
-    bf16x8 qf[2];
+  constexpr int QT = (MAXT + FWD_WAVES - 1) / FWD_WAVES;   // query tiles per wave
+  // Q fragments of ALL this wave's query tiles first, then the K / V images: one exposed HBM latency per workgroup
+  bf16x8 qall[QT][2];
+#pragma unroll
+  for (int it = 0; it < QT; ++it) {
+    const int q_ = (wave + it * FWD_WAVES) * 16 + lc;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[kk] = q < N ? *(const bf16x8*)(qbase + (size_t)q * rs + kk * 32 + g * 8) : z;
+      qall[it][kk] = (wave + it * FWD_WAVES < ntile && q_ < N) ? *(const bf16x8*)(qbase + (size_t)q_ * rs + kk * 32 + g * 8) : z;
     }
+  }
+  load_image<FWD_WAVES * 64>(k_img, qbase + D, rs, N, 1.0f, tid);
+  load_image<FWD_WAVES * 64>(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
+  __syncthreads();
+  const int tmask = N >> 4;                          // first key tile that contains a key >= N
+
+#pragma unroll
+  for (int it = 0; it < QT; ++it) {
+    const int qt = wave + it * FWD_WAVES;
+    if (qt >= ntile) break;
+    const int q = qt * 16 + lc;                      // this lane's query
     f32x4 s[MAXT + 1];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) s[t] = mfma16(img_row_frag(k_img, t * 16, kk, lane), qf[kk], s[t]);
+      for (int kk = 0; kk < 2; ++kk) s[t] = mfma16(img_row_frag(k_img, t * 16, kk, lane), qall[it][kk], s[t]);
     }
+    // raw-score row max (scale > 0); only tiles >= tmask can hold padded keys
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)
+    for (int t = 0; t < MAXT; ++t) {
+      if (t >= tmask) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[t][r] = (t * 16 + g * 4 + r < N) ? s[t][r] * c2 : -INFINITY;
-        mx = fmaxf(mx, s[t][r]);
+        for (int r = 0; r < 4; ++r)
+          if (t * 16 + g * 4 + r >= N) s[t][r] = -INFINITY;
       }
+      mx = fmaxf(fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])), mx);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[t][r] = exp2f(s[t][r] - mx);
+        s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, -mxs));   // exp2(-inf) = 0 for padded keys
         sum += s[t][r];
       }
     s[MAXT] = (f32x4){0.f, 0.f, 0.f, 0.f};           // keys 208..223
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    if (a.lse && g == 0 && q < N) a.lse[((size_t)b * a.H + h) * N + q] = (mx + log2f(sum)) * 0.6931471805599453f;
+    if (a.lse && g == 0 && q < N) a.lse[((size_t)b * a.H + h) * N + q] = (mxs + log2f(sum)) * 0.6931471805599453f;
 
     f32x4 o[4];
 #pragma unroll
@@ -221,25 +237,35 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
   load_image<BWD_WAVES * 64>(do_img, dobase, (size_t)D, N, gate, tid);
   // zero both dS^T buffers once: key rows of tiles that are never written (>= ntile) must read as 0 in dQ
   for (int i = tid; i < 2 * DST_BYTES / 16; i += BWD_WAVES * 64) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (tid < KROWS) {
-    float l2 = 0.f, dl = 0.f;
-    if (tid < N) {
-      l2 = a.lse[((size_t)b * a.H + h) * N + tid] * 1.4426950408889634f;
-      const __bf16* dr = dobase + (size_t)tid * D;
-      const __bf16* orow = obase + (size_t)tid * D;
-      bf16x8 x[8], y[8];
+  // lse (log2 domain) and delta[q] = sum_d dO[q][d] O[q][d]: 8 lanes per row, one 16-byte chunk each; all loads
+  // are issued before the first use (one exposed latency)
+  {
+    constexpr int DIT = (KROWS * 8 + BWD_WAVES * 64 - 1) / (BWD_WAVES * 64);
+    bf16x8 xd[DIT], yd[DIT];
+    float ls[DIT];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        x[c] = *(const bf16x8*)(dr + c * 8);
-        y[c] = *(const bf16x8*)(orow + c * 8);
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += bf2f(x[c][e]) * bf2f(y[c][e]);
+    for (int it = 0; it < DIT; ++it) {
+      const int idx = tid + it * BWD_WAVES * 64, row = idx >> 3, c = idx & 7;
+      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      const bool ok = row < N;
+      xd[it] = ok ? *(const bf16x8*)(dobase + (size_t)row * D + c * 8) : z;
+      yd[it] = ok ? *(const bf16x8*)(obase + (size_t)row * D + c * 8) : z;
+      ls[it] = (ok && c == 0) ? a.lse[((size_t)b * a.H + h) * N + row] * 1.4426950408889634f : 0.f;
     }
-    lse2[tid] = l2;
-    delta[tid] = dl;
+#pragma unroll
+    for (int it = 0; it < DIT; ++it) {
+      const int idx = tid + it * BWD_WAVES * 64, row = idx >> 3, c = idx & 7;
+      float dl = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += bf2f(xd[it][e]) * bf2f(yd[it][e]);
+      dl += __shfl_xor(dl, 1, 64);
+      dl += __shfl_xor(dl, 2, 64);
+      dl += __shfl_xor(dl, 4, 64);
+      if (c == 0 && row < KROWS) {
+        delta[row] = dl;
+        lse2[row] = ls[it];
+      }
+    }
   }
   __syncthreads();
 
@@ -387,7 +413,7 @@ extern "C" int devit_attn_fwd(const void* qkv, void* out, float* lse, const floa
     attr_set = true;
   }
   AttnFwdArgs a{(const __bf16*)qkv, (__bf16*)out, lse, head_gate, B, N, H, scale};
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), FWD_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(FWD_WAVES * 64), FWD_LDS, (hipStream_t)stream, a);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }

@@ -185,22 +185,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   }
 }
 
-// out_k[c] (+)= sum_p partial[p][k][c], k = 0..2  (deterministic order; 32 columns x 8 part-groups per block)
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* partial, int nparts, int D, float* out0,
-                                                              float* out1, float* out2, int accumulate) {
-  __shared__ float red[8][32];
+// out_k[c] (+)= sum_p partial[p][k][c], k = 0..2  (deterministic order; 32 columns x 32 part-groups per block)
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* partial, int nparts, int D, float* out0,
+                                                               float* out1, float* out2, int accumulate) {
+  __shared__ float red[32][33];
   const int ncols = 3 * D;
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  if (c < ncols)
-    for (int p = grp; p < nparts; p += 8) s += partial[(size_t)p * ncols + c];
+  if (c < ncols) {
+#pragma unroll 4
+    for (int p = grp; p < nparts; p += 32) s += partial[(size_t)p * ncols + c];
+  }
   red[grp][cl] = s;
   __syncthreads();
   if (grp == 0 && c < ncols) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i][cl];
+    for (int i = 0; i < 32; ++i) t += red[i][cl];
     float* dst = c < D ? out0 + c : (c < 2 * D ? out1 + (c - D) : (out2 ? out2 + (c - 2 * D) : nullptr));
     if (dst) *dst = accumulate ? *dst + t : t;
   }
@@ -263,7 +265,7 @@ extern "C" int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x
   });
   DEVIT_CHECK(rc == 0, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: unsupported D=%d", D);
   DEVIT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((3 * D + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((3 * D + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
                      (const float*)workspace, grid, D, dgamma, dbeta, dx_bf16_colsum, accumulate);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
