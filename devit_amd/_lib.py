@@ -57,6 +57,7 @@ SIGNATURES = {
     "devit_sumsq_f32": (_I, [_P, _Z, _P, _P, _Z, _P]),
     "devit_adamw_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _F, _P]),
     "devit_cls_distill_loss": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "devit_token_mse": (_I, [_P, _P, _Z, _P, _P, _I, _P]),
     "devit_relation_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "devit_relation_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "devit_gemm_f32": (_I, [_P, _LL, _LL, _LL, _LL, _P, _LL, _LL, _LL, _LL, _I, _I, _I, _I, _I, _LL, _LL, _I, _I, _F, _P, _I,

@@ -146,7 +146,15 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* A, long l
     const float* a = A + m * sam;
     const float* b = B + n * sbn;
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s = fmaf(a[k * sak], b[k * sbk], s);
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {       // 16 independent loads in flight, then the fmaf chain in k order
+      float av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { av[u] = a[(k + u) * sak]; bv[u] = b[(k + u) * sbk]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s = fmaf(av[u], bv[u], s);
+    }
+    for (; k < K; ++k) s = fmaf(a[k * sak], b[k * sbk], s);
     s = s * alpha + (bias ? bias[n] : 0.f);
     float* c = C + (size_t)m * ldc + n;
     *c = accumulate ? *c + s : s;

@@ -228,7 +228,36 @@ __global__ __launch_bounds__(256) void rel_grad_kernel(const RelGradArgs a) {
   else ((__bf16*)a.S)[o] = f2bf(v);
 }
 
+// ---- token MSE (nn.MSELoss, utils/losses.py:194,228,241-242): loss (+)= mean((a-b)^2), da = 2 (a-b) / n ---------
+__global__ __launch_bounds__(1024) void mse_kernel(const float* a, const float* b, size_t n, float* loss, float* da,
+                                                   int accumulate) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const float inv = 1.0f / (float)n;
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    const float d = a[i] - b[i];
+    s += d * d;
+    if (da) da[i] = 2.0f * d * inv;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    loss[0] = (accumulate ? loss[0] : 0.f) + t * inv;
+  }
+}
+
 }  // namespace
+
+extern "C" int devit_token_mse(const float* a, const float* b, size_t n, float* loss, float* da, int accumulate,
+                               void* stream) {
+  DEVIT_CHECK(a && b && loss && n > 0, DEVIT_ERR_ARG, "devit_token_mse: bad argument");
+  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, loss, da, accumulate);
+  DEVIT_LAUNCH_CHECK();
+  return DEVIT_OK;
+}
 
 extern "C" int devit_cls_distill_loss(const float* logits, const float* logits_kd, const float* teacher_logits,
                                       const float* soft_targets, int B, int C, int kind, float alpha, float tau,

@@ -144,3 +144,74 @@ def evaluate(data_loader, model, device):
         metric_logger.meters['acc5'].update(acc5.item(), n=images.shape[0])
     metric_logger.synchronize_between_processes()
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+# ------------------------------------------------------------------------------------------------------
+# ensemble stage (engine.py:143-242): MultiViT backbones + EnsMLP fusion against the teacher
+# ------------------------------------------------------------------------------------------------------
+def ens_forward(model, ens_model, criterion, samples, targets, distillation_type="hard"):
+    """engine.py:167-179: returns dict(loss, token_loss, cls_loss)."""
+    features = model(samples)
+    if distillation_type == 'none':
+        logits = ens_model(features)
+        loss = criterion(samples, logits, targets)
+        return dict(loss=loss, token_loss=None, cls_loss=loss)
+    outputs = ens_model(features, True)
+    inter_loss, cls_loss = criterion(inputs=samples, stu_outputs=outputs, labels=targets)
+    return dict(loss=inter_loss + cls_loss, token_loss=inter_loss, cls_loss=cls_loss)
+
+
+def train_1epoch_ens_disjoint(model, ens_model, criterion, data_loader, optimizer, ens_optimizer, device, epoch, scaler,
+                              args, log, model_ema=None, ens_model_ema=None, mixup_fn=None, max_norm=0, print_freq=10):
+    """engine.py:143-210.  `optimizer` / `ens_optimizer` are any torch optimizers over the two parameter sets (the
+    reference uses two AdamW instances); gradients arrive in param.grad."""
+    from .utils import MetricLogger, SmoothedValue
+    model.train(True)
+    ens_model.train(True)
+    metric_logger = MetricLogger(delimiter="  ")
+    for name in ('backbone_lr', 'ens_lr', 'cls_loss', 'token_loss'):
+        metric_logger.add_meter(name, SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    step = 0
+    for samples, targets in metric_logger.log_every(data_loader, print_freq, 'Epoch: [{}]'.format(epoch)):
+        samples, targets = samples.to(device, non_blocking=True), targets.to(device, non_blocking=True)
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)
+        optimizer.zero_grad(set_to_none=True)
+        ens_optimizer.zero_grad(set_to_none=True)
+        out = ens_forward(model, ens_model, criterion, samples, targets, args.distillation_type)
+        out['loss'].backward()
+        if max_norm:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+            torch.nn.utils.clip_grad_norm_(ens_model.parameters(), max_norm)
+        optimizer.step()
+        ens_optimizer.step()
+        if step % print_freq == 0:
+            lv = out['loss'].item()
+            if not math.isfinite(lv):
+                print(f"Loss is {lv}, stopping training")
+                sys.exit(1)
+            metric_logger.update(loss=lv, backbone_lr=optimizer.param_groups[0]["lr"], ens_lr=ens_optimizer.param_groups[0]["lr"])
+            if out['token_loss'] is not None:
+                metric_logger.update(token_loss=out['token_loss'].item(), cls_loss=out['cls_loss'].item())
+        step += 1
+    metric_logger.synchronize_between_processes()
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def evaluate_ens_disjoint(data_loader, model, ens_model, device):
+    """engine.py:212-242: collaborative inference = N sub-model backbones + EnsMLP, CE, top-1 / top-5."""
+    from .utils import MetricLogger, accuracy
+    metric_logger = MetricLogger(delimiter="  ")
+    model.eval()
+    ens_model.eval()
+    for images, target in metric_logger.log_every(data_loader, 10, 'Test:'):
+        images, target = images.to(device, non_blocking=True), target.to(device, non_blocking=True)
+        output = ens_model(model(images))
+        loss = losses.DistillLoss(losses.SoftTargetCrossEntropy(), 'none', 0., 1.)(output, None, target)
+        acc1, acc5 = accuracy(output, target, topk=(1, 5))
+        metric_logger.update(loss=loss.item())
+        metric_logger.meters['acc1'].update(acc1.item(), n=images.shape[0])
+        metric_logger.meters['acc5'].update(acc5.item(), n=images.shape[0])
+    metric_logger.synchronize_between_processes()
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

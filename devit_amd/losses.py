@@ -119,3 +119,48 @@ class LabelSmoothingCrossEntropy(nn.Module):
         C = x.shape[-1]
         soft = torch.full_like(x, self.smoothing / C).scatter_(1, target[:, None], self.confidence + self.smoothing / C)
         return ops.ClsDistillLossFn.apply(x, x, torch.zeros_like(x), soft, "none", 0.0, 1.0)
+
+
+class _TokenMseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        from ._lib import call, ptr, stream_ptr
+        L.require_device(a)
+        a, b = a.contiguous().float(), b.contiguous().float()
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        da = torch.empty_like(a)
+        call("devit_token_mse", ptr(a), ptr(b), a.numel(), ptr(loss), ptr(da), 0, stream_ptr())
+        ctx.save_for_backward(da)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        da, = ctx.saved_tensors
+        return da * g, None
+
+
+class EnsLoss(nn.Module):
+    """utils/losses.py:180-244: (token_loss, cls_loss) of the ensemble stage.  The teacher forward runs inside, under
+    no_grad, with distill_token=True (:222-227)."""
+
+    def __init__(self, base_criterion, teacher_model, model, distillation_type, alpha, tau, loss_type='mse'):
+        super().__init__()
+        if loss_type != 'mse':
+            raise NotImplementedError("EnsLoss: only loss_type='mse' is on the DeViT path (ensemble.py default)")
+        self.base_criterion, self.teacher_model, self.model = base_criterion, teacher_model, model
+        self.distillation_type, self.alpha, self.tau = distillation_type, alpha, tau
+        self._cls = DistillLoss(base_criterion if isinstance(base_criterion, (SoftTargetCrossEntropy, nn.CrossEntropyLoss))
+                                else SoftTargetCrossEntropy(), distillation_type, alpha, tau)
+
+    def forward(self, inputs, stu_outputs, labels):
+        if self.distillation_type == 'none':
+            return self._cls(stu_outputs, None, labels)
+        with torch.no_grad():
+            tea = self.teacher_model(inputs, distill_token=True)
+        tokens, stu_logits = stu_outputs
+        cls_loss = self._cls(stu_logits, tea['output'], labels)          # (1-a) base + a distill, :236-237
+        if 'vit' in self.model:
+            return _TokenMseFn.apply(tokens, tea['last_tokens']), cls_loss
+        cls_token, dist_token = tokens
+        tea_token, tea_token_dist = tea['last_tokens']
+        return _TokenMseFn.apply(cls_token, tea_token) + _TokenMseFn.apply(dist_token, tea_token_dist), cls_loss

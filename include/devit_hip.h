@@ -194,6 +194,10 @@ int devit_cls_distill_loss(const float* logits, const float* logits_kd, const fl
                            const float* soft_targets, int B, int C, int kind, float alpha, float tau, float* loss3,
                            float* dlogits, float* dlogits_kd, void* stream);
 
+/* Token feature-matching loss of the ensemble stage (EnsLoss, utils/losses.py:194,228,241-242: nn.MSELoss):
+ * loss[0] (+)= mean((a - b)^2); da (optional) = 2 (a - b) / n. */
+int devit_token_mse(const float* a, const float* b, size_t n, float* loss, float* da, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * q/k/v feature-relation loss (utils/losses.py:307-328).  The per-image Grams F F^T run on
  * devit_gemm_bf16 (batched, padded to 256x256, DEVIT_EPI_STORE_F32); these two kernels do the rest:

@@ -222,3 +222,36 @@ def distill_step(st_s, geom_s, st_t, geom_t, img, soft_targets, gama=(0.2, 0.1, 
     loss = cls_loss + gama[0] * q_loss + gama[1] * k_loss + gama[2] * v_loss   # :105-106
     return {"loss": loss, "cls_loss": cls_loss, "q_loss": q_loss, "k_loss": k_loss, "v_loss": v_loss,
             "student": so, "teacher": to}
+
+
+# ----------------------------------------------------------------------------
+# ensemble stage (models/ensemble_models.py, utils/losses.py:180-244)
+# ----------------------------------------------------------------------------
+def make_ens_state(tag="ENS", sum_dim=1536, teacher_size=768, num_class=100):
+    """EnsMLP weights in the reference's registration order (models/ensemble_models.py:55-63)."""
+    shapes = [("cls_mlp.weight", (teacher_size, sum_dim)), ("cls_mlp.bias", (teacher_size,)),
+              ("cls_classifier.weight", (num_class, teacher_size)), ("cls_classifier.bias", (num_class,)),
+              ("dist_mlp.weight", (teacher_size, sum_dim)), ("dist_mlp.bias", (teacher_size,)),
+              ("dist_classifier.weight", (num_class, teacher_size)), ("dist_classifier.bias", (num_class,))]
+    return OrderedDict((k, torch.from_numpy(det_array(f"{tag}/{k}", sh, std=0.02))) for k, sh in shapes)
+
+
+def ens_forward(sub_states, geom, ens, img, training=False):
+    """MultiViT.forward (:32-40) + EnsMLP.forward (:65-90) for distilled ('deit') sub-models.
+    Returns ((cls_token, dist_token), logits)."""
+    feats = [forward(st, geom, img, training=training)["last_tokens"] for st in sub_states]
+    cls_cat = torch.stack([f[0] for f in feats], 1).reshape(img.shape[0], -1)      # :77
+    dist_cat = torch.stack([f[1] for f in feats], 1).reshape(img.shape[0], -1)     # :78
+    ct = F.linear(cls_cat, ens["cls_mlp.weight"], ens["cls_mlp.bias"])             # :80-81
+    dt = F.linear(dist_cat, ens["dist_mlp.weight"], ens["dist_mlp.bias"])
+    logits = (F.linear(ct, ens["cls_classifier.weight"], ens["cls_classifier.bias"]) +
+              F.linear(dt, ens["dist_classifier.weight"], ens["dist_classifier.bias"])) / 2    # :84-86
+    return (ct, dt), logits
+
+
+def ens_loss(tokens, logits, teacher_out, soft_targets, kind="hard", alpha=0.5, tau=1.0):
+    """EnsLoss.forward, 'deit' branch (utils/losses.py:233-244) -> (token_loss, cls_loss)."""
+    tea_cls, tea_dist = teacher_out["last_tokens"]
+    cls_loss = distill_cls_loss(logits, logits, teacher_out["output"], soft_targets, kind, alpha, tau)
+    token_loss = F.mse_loss(tokens[0], tea_cls) + F.mse_loss(tokens[1], tea_dist)
+    return token_loss, cls_loss

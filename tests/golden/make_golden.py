@@ -72,9 +72,9 @@ def install_shims():
         registry[fn.__name__] = fn
         return fn
 
-    def create_model(name, pretrained=False, **kw):
+    def create_model(model_name, pretrained=False, **kw):
         kw = {k: v for k, v in kw.items() if v is not None}
-        return registry[name](pretrained=pretrained, **kw)
+        return registry[model_name](pretrained=pretrained, **kw)
 
     def trunc_normal_(t, mean=0., std=1., a=-2., b=2.):
         return nn.init.trunc_normal_(t, mean, std, a, b)
@@ -141,12 +141,61 @@ def load_into(model, st):
     model.load_state_dict(st)
 
 
+def ens_state(tag="ENS"):
+    """Deterministic EnsMLP weights in the reference's registration order (models/ensemble_models.py:55-63)."""
+    shapes = [("cls_mlp.weight", (768, 1536)), ("cls_mlp.bias", (768,)), ("cls_classifier.weight", (100, 768)),
+              ("cls_classifier.bias", (100,)), ("dist_mlp.weight", (768, 1536)), ("dist_mlp.bias", (768,)),
+              ("dist_classifier.weight", (100, 768)), ("dist_classifier.bias", (100,))]
+    return {k: torch.from_numpy(det_array(f"{tag}/{k}", sh, std=0.02)) for k, sh in shapes}
+
+
+def make_ensemble(create_model, de_vit, ref_losses):
+    """ensemble stage (config 5): MultiViT(4 x dedeit) + EnsMLP + EnsLoss on bs 4, C = 100."""
+    import models.ensemble_models as em          # reference
+    gs, gt = O.GEOMETRY["dedeit"], O.GEOMETRY["deit_base_distilled_patch16_224"]
+    multi = em.MultiViT(model="dedeit", drop=0, drop_path=0.0, num_classes_list=[25] * 4, num_div=4)
+    ens = em.EnsMLP(model="dedeit", num_class=100, sub_size=384, num_classes_list=[25] * 4, teacher_size=768)
+    sd = multi.state_dict()
+    keys = list(sd.keys())
+    for i in range(4):                            # positional copy like ensemble.py:192-200,229-238
+        sub = O.make_state(gs, 25, f"E{i}")
+        src = list(sub.keys())
+        for j in range(len(src) - 4):
+            sd[keys[i * (len(src) - 4) + j]] = sub[src[j]]
+    multi.load_state_dict(sd)
+    ens.load_state_dict(ens_state())
+    teacher = de_vit.VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                                       norm_layer=functools.partial(nn.LayerNorm, eps=1e-6), distilled=True, num_classes=100)
+    teacher.load_state_dict(O.make_state(gt, 100, "T100"))
+    teacher.eval()
+    img = torch.from_numpy(det_array("img4", (4, 3, 224, 224)))
+    multi.eval(); ens.eval()
+    with torch.no_grad():
+        logits_eval = ens(multi(img))
+    multi.train(); ens.train()
+    feats = multi(img)
+    tokens, logits = ens(feats, True)
+    y = det_labels("ens_y", 4, 100)
+    soft = torch.full((4, 100), 0.1 / 100).scatter_(1, torch.from_numpy(y)[:, None], 0.9 + 0.1 / 100)
+    crit = ref_losses.EnsLoss(sys.modules["timm.loss"].SoftTargetCrossEntropy(), teacher, "dedeit", "hard", 0.5, 1.0)
+    token_loss, cls_loss = crit(img, (tokens, logits), soft)
+    (token_loss + cls_loss).backward()
+    save("ensemble", logits_eval=logits_eval, logits_train=logits, tok_cls=tokens[0], tok_dist=tokens[1],
+         token_loss=token_loss, cls_loss=cls_loss, soft_targets=soft,
+         g_cls_mlp_w_rows=ens.cls_mlp.weight.grad[::48], g_dist_cls_w=ens.dist_classifier.weight.grad[::10],
+         g_b2_fc1_rows=multi.backbones[2].blocks[3].mlp.fc1.weight.grad[::96],
+         g_b0_pos=multi.backbones[0].pos_embed.grad[0, ::16], n_multi_keys=np.array(len(keys)))
+
+
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(0)
     _, create_model, _ = install_shims()
     import models.de_vit as de_vit          # noqa: E402  (reference)
     import utils.losses as ref_losses       # noqa: E402  (reference)
+    if "--only-ensemble" in sys.argv:
+        make_ensemble(create_model, de_vit, ref_losses)
+        return
 
     C = 25
     gs, gt = O.GEOMETRY["dedeit"], O.GEOMETRY["deit_base_distilled_patch16_224"]
@@ -298,6 +347,7 @@ def main():
          g_norm_w=grads["norm.weight"].grad, g_ln1_5_b=grads["blocks.5.norm1.bias"].grad)
     with open(os.path.join(HERE, "step_param_names.json"), "w") as f:
         json.dump(names, f)
+    make_ensemble(create_model, de_vit, ref_losses)
     print("done")
 
 

@@ -27,3 +27,19 @@ def test_distill_sub_cli(tmp_path):
     import json
     line = json.loads(open(os.path.join(out, "log.txt")).read().splitlines()[-1])
     assert line["train_loss"] == line["train_loss"] and line["n_parameters"] == 21685682   # finite, C = 25
+
+
+def test_ensemble_cli(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import ensemble
+    parser = argparse.ArgumentParser(parents=[ensemble.get_args_parser()], conflict_handler='resolve')
+    args = parser.parse_args(["--synthetic", "2", "--batch-size", "4", "--epochs", "1", "--model", "dedeit",
+                              "--teacher-model", "deit_base_distilled_patch16_224", "--output_dir", str(tmp_path)])
+    args.output_dir = str(tmp_path)
+    ensemble.main(args)
+    assert os.path.exists(os.path.join(str(tmp_path), "checkpoint_temp.pth"))
+    import json
+    line = json.loads(open(os.path.join(str(tmp_path), "log.txt")).read().splitlines()[-1])
+    assert line["train_loss"] == line["train_loss"] and "test_acc1" in line

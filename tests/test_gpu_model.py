@@ -234,3 +234,43 @@ def test_f32_path_meets_1e3_bar(golden, models, dev):
         s.precision = t.precision = "bf16"
         for p in s.parameters():
             p.grad = None
+
+
+# ------------------------------------------------------------------------------------------ ensemble stage (config 5)
+def test_ensemble_vs_golden(golden, dev):
+    """MultiViT(4 x dedeit) + EnsMLP + EnsLoss against the reference's own modules (models/ensemble_models.py,
+    utils/losses.py:180-244), including the positional checkpoint copy of ensemble.py:192-200."""
+    import devit_amd
+    from devit_amd import engine, losses
+    from devit_amd.ensemble_models import EnsMLP, MultiViT, load_sub_checkpoints
+    g = golden("ensemble")
+    multi = MultiViT("dedeit", drop=0, drop_path=0.0, num_classes_list=[25] * 4, num_div=4)
+    assert len(multi.state_dict()) == int(g["n_multi_keys"])
+    load_sub_checkpoints(multi, [O.make_state(GS, 25, f"E{i}") for i in range(4)])
+    ens = EnsMLP("dedeit", 100, 384, [25] * 4, 768)
+    ens.load_state_dict(O.make_ens_state())
+    teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=100)
+    teacher.load_state_dict(O.make_state(GT, 100, "T100"))
+    multi.to(dev); ens.to(dev); teacher.to(dev).eval()
+    img = torch.from_numpy(det_array("img4", (4, 3, 224, 224))).to(dev)
+    multi.eval(); ens.eval()
+    with torch.no_grad():
+        le = ens(multi(img))
+    assert rel(le, g["logits_eval"]) < 3e-2 and np.array_equal(le.argmax(1).cpu().numpy(), g["logits_eval"].argmax(1))
+    multi.train(); ens.train()
+    crit = losses.EnsLoss(losses.SoftTargetCrossEntropy(), teacher, "dedeit", "hard", 0.5, 1.0)
+    out = engine.ens_forward(multi, ens, crit, img, torch.from_numpy(g["soft_targets"]).to(dev))
+    assert abs(float(out["token_loss"]) - float(g["token_loss"])) < 2e-2 * float(g["token_loss"])
+    assert abs(float(out["cls_loss"]) - float(g["cls_loss"])) < 2e-2 * float(g["cls_loss"])
+    out["loss"].backward()
+    assert rel(ens.cls_mlp.weight.grad[::48], g["g_cls_mlp_w_rows"]) < 6e-2
+    assert rel(ens.dist_classifier.weight.grad[::10], g["g_dist_cls_w"]) < 6e-2
+    assert rel(multi.backbones[2].blocks[3].mlp.fc1.weight.grad[::96], g["g_b2_fc1_rows"]) < 6e-2
+    assert rel(multi.backbones[0].pos_embed.grad[0, ::16], g["g_b0_pos"]) < 6e-2
+    # exact-fp32 path on the same graph: the 1e-3 bar
+    for m in list(multi.backbones) + [teacher]:
+        m.precision = "f32"
+    multi.eval(); ens.eval()
+    with torch.no_grad():
+        le = ens(multi(img))
+    assert rel(le, g["logits_eval"]) < 1e-3

@@ -140,3 +140,24 @@ def test_distill_step(golden, states, img):
     close(st_s["blocks.0.mlp.fc1.weight"].grad[::64], g["g_fc1_0_rows"], rtol=1e-4)
     close(st_s["pos_embed"].grad[0, ::8], g["g_pos"], rtol=1e-4)
     close(st_s["patch_embed.proj.weight"].grad[::16].reshape(-1, 768), g["g_patch_w"], rtol=1e-4)
+
+
+def test_ensemble_stage(golden):
+    """MultiViT + EnsMLP + EnsLoss restatement vs the reference's own modules (config 5 path)."""
+    g = golden("ensemble")
+    subs = [O.make_state(GS, 25, f"E{i}") for i in range(4)]
+    ens = {k: v.clone().requires_grad_(True) for k, v in O.make_ens_state().items()}
+    img = torch.from_numpy(det_array("img4", (4, 3, 224, 224)))
+    with torch.no_grad():
+        _, le = O.ens_forward(subs, GS, ens, img, training=False)
+    close(le, g["logits_eval"], rtol=5e-5)
+    tokens, logits = O.ens_forward(subs, GS, ens, img, training=True)
+    close(logits, g["logits_train"], rtol=5e-5); close(tokens[0], g["tok_cls"], rtol=5e-5); close(tokens[1], g["tok_dist"], rtol=5e-5)
+    with torch.no_grad():
+        tea = O.forward(O.make_state(GT, 100, "T100"), GT, img, training=False)
+    tl, cl = O.ens_loss(tokens, logits, tea, torch.from_numpy(g["soft_targets"]))
+    close(tl, g["token_loss"], rtol=2e-5); close(cl, g["cls_loss"], rtol=2e-5)
+    (tl + cl).backward()
+    close(ens["cls_mlp.weight"].grad[::48], g["g_cls_mlp_w_rows"], rtol=1e-4)
+    close(ens["dist_classifier.weight"].grad[::10], g["g_dist_cls_w"], rtol=1e-4)
+    assert int(g["n_multi_keys"]) == 604
