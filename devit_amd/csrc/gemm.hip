@@ -40,30 +40,48 @@ __device__ __forceinline__ int phys_row(int r, int group, int skip) {
 // Issue this wave's LDS-DMA loads (1 KiB each) for one operand tile of width W (128 or 256).
 //   KM == false: operand stored [R][K]; `org` = &op[row0][0]; LDS image [W rows][64 k] (128-B rows)
 //   KM == true : operand stored [K][R]; `org` = &op[0][col0]; LDS image [64 k][W cols] (2W-B rows)
+// The address is split into a wave-uniform base that advances with k0 (SGPRs) and a per-lane 32-bit byte offset
+// that is loop-invariant, so the K-loop issues `global_load_lds_dwordx4 voff, s[base]` with no per-step VALU math.
+template <bool KM, int W, int NWAVES>
+__device__ __forceinline__ unsigned lane_offset(int ld, int wave, int lane, int i) {
+  constexpr int CNT = (W / 8) / NWAVES;
+  const int slab = wave * CNT + i;
+  if (!KM) {
+    const int row = slab * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    return (unsigned)(row * ld + chunk * 8) * 2u;
+  } else {
+    constexpr int LPR = W / 8, RPS = 64 / LPR;  // lanes per k-row, k-rows per 1-KiB slab
+    const int krow = slab * RPS + lane / LPR;
+    const int h = (krow & 3) | (((krow >> 3) & 1) << 2);
+    const int chunk = (lane % LPR) ^ (h << 1);
+    return (unsigned)(krow * ld + chunk * 8) * 2u;
+  }
+}
+
 template <bool KM, int W, int NWAVES>
 __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, int group, int skip,
                                            char* lds_tile, int wave, int lane) {
   constexpr int CNT = (W / 8) / NWAVES;
+  if (KM && group > 0) {   // row-remapped reduction index (patch-embed wgrad): per-lane physical rows, generic path
 #pragma unroll
-  for (int i = 0; i < CNT; ++i) {
-    const int slab = wave * CNT + i;
-    const __bf16* src;
-    if (!KM) {
-      const int row = slab * 8 + (lane >> 3);
-#ifdef DEVIT_GEMM_NOSWZ
-      const int chunk = (lane & 7);
-#else
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-#endif
-      src = org + (size_t)row * ld + k0 + chunk * 8;
-    } else {
-      constexpr int LPR = W / 8, RPS = 64 / LPR;  // lanes per k-row, k-rows per 1-KiB slab
+    for (int i = 0; i < CNT; ++i) {
+      constexpr int LPR = W / 8, RPS = 64 / LPR;
+      const int slab = wave * CNT + i;
       const int krow = slab * RPS + lane / LPR;
       const int h = (krow & 3) | (((krow >> 3) & 1) << 2);
       const int chunk = (lane % LPR) ^ (h << 1);
-      src = org + (size_t)phys_row(k0 + krow, group, skip) * ld + chunk * 8;
+      const __bf16* src = org + (size_t)phys_row(k0 + krow, group, skip) * ld + chunk * 8;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + slab * 1024), 16, 0, 0);
     }
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + slab * 1024), 16, 0, 0);
+    return;
+  }
+  const char* ubase = (const char*)org + (size_t)k0 * (KM ? (size_t)ld : (size_t)1) * 2;   // wave-uniform
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    const int slab = wave * CNT + i;
+    const unsigned off = lane_offset<KM, W, NWAVES>(ld, wave, lane, i);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(ubase + off), LDS_PTR(lds_tile + slab * 1024), 16, 0, 0);
   }
 }
 
