@@ -1,16 +1,13 @@
 // bf16 MFMA GEMM for gfx950 with fused epilogues.  C[M,N] = sum_k A(m,k) B(n,k).
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 MFMA 16x16x32
-// accumulators.  Operand tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-// wave-instruction), double buffered (2 x 32 KiB), one barrier per K-step.  The LDS image is
-// lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and undone
-// by the same XOR on the fragment read (cdna_hip_programming.md §5.4 rule 21):
-//   k-contiguous operand  [128 rows][64 k]  (128-B rows):  chunk16 ^= (row >> 1) & 7   -> ds_read_b128
-//   k-major operand       [64 k][128 cols]  (256-B rows):  chunk16 ^= h(k) << 1,
-//                         h(k) = (k & 3) | ((k >> 3) & 1) << 2                          -> ds_read_b64_tr_b16
-// Both are conflict-free for the MFMA 16x16x32 fragment maps (derivation in DESIGN.md §4.1).
-// The accumulator tile is staged through LDS (reusing the operand buffers) so that every epilogue
-// reads/writes global memory in whole 128/256-byte row segments.
+// Tiles 128x128x64 (4 waves, two workgroups per CU) or 256x256x64 (8 waves), each wave a 64x64 / 128x64 sub-tile of
+// MFMA 16x16x32 accumulators.  Operand tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+// wave-instruction) into a ring of stages, one raw barrier per K-step with the newest stages still in flight
+// (counted vmcnt).  The LDS image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
+// address and undone by the same XOR on the fragment read (cdna_hip_programming.md §5.4 rule 21): swz_row() for
+// k-contiguous operands (ds_read_b128 fragments), swz_krow() for k-major operands (ds_read_b64_tr_b16 fragments).
+// Epilogues run straight from the accumulators (epilogue_direct): the MFMAs take the weight operand on their row
+// side so each lane owns consecutive output columns; only the split-K atomic epilogue stages through LDS.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -21,6 +18,25 @@ namespace {
 
 constexpr int BK = 64;
 
+// n / d for 0 <= n < 2^31 by multiply-shift (Granlund-Montgomery round-up): three SALU ops instead of the
+// float-reciprocal sequence hipcc emits for a scalar division.  Host-initialised.
+struct FastDiv {
+  unsigned mul, shift;
+  int d;
+};
+__host__ inline FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = d;
+  unsigned s = 0;
+  while ((1ll << s) < d) ++s;
+  f.shift = 31 + s;
+  f.mul = (unsigned)(((1ull << f.shift) / (unsigned long long)d) + 1ull);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+  return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.shift);
+}
+
 struct GemmArgs {
   const __bf16* A;
   const __bf16* B;
@@ -28,7 +44,8 @@ struct GemmArgs {
   int a_group, a_skip, b_group, b_skip;
   long long a_bs, b_bs;
   int M, N, K;
-  int tiles_m, tiles_n, split_k;
+  int tiles_m, tiles_n, split_k, total_tiles;
+  FastDiv d_per_z, d_chunk, d_gn, d_last, d_split;   // tiles per z-slice, per n-chunk; chunk widths; split_k
   int gn;  // n-tiles per L2 chunk: tiles are ordered chunk-major, then m, then n inside the chunk
   devit_epilogue ep;
 };
@@ -36,6 +53,16 @@ struct GemmArgs {
 __device__ __forceinline__ int phys_row(int r, int group, int skip) {
   return group > 0 ? r + skip * (r / group + 1) : r;
 }
+
+// LDS image swizzles (applied to the DMA's source address and again on the fragment reads; the LDS side of an LDS-DMA
+// is lane-linear).  16-byte chunk index XOR:
+//   row-major image [rows][64 k], 128-B rows: by row bits (1, 2^4, 3) -- conflict-free ds_read_b128 both for 16
+//     consecutive rows and for the PAIRED row set {0-3, 8-11, 16-19, 24-27} (+4 for odd tiles), see tile_row();
+//   k-major image [64 k][W], read by ds_read_b64_tr_b16 (lane 4q+p: k-row q, four columns): k-row bits (0,1) go to
+//     chunk bits (2,3) and k-row bit 3 to chunk bit 1 -- the sixteen 8-byte pieces of a 16-lane group land on distinct
+//     banks whether its four column groups are adjacent (natural) or 16 bytes apart (PAIRED); k-rows r and r+4 share it.
+__device__ __forceinline__ int swz_row(int row) { return ((row >> 1) & 7) ^ (((row >> 4) & 1) << 1); }
+__device__ __forceinline__ int swz_krow(int krow) { return ((krow & 3) << 2) | (((krow >> 3) & 1) << 1); }
 
 // Issue this wave's LDS-DMA loads (1 KiB each) for one operand tile of width W (128 or 256).
 //   KM == false: operand stored [R][K]; `org` = &op[row0][0]; LDS image [W rows][64 k] (128-B rows)
@@ -48,184 +75,334 @@ __device__ __forceinline__ unsigned lane_offset(int ld, int wave, int lane, int 
   const int slab = wave * CNT + i;
   if (!KM) {
     const int row = slab * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int chunk = (lane & 7) ^ swz_row(row);
     return (unsigned)(row * ld + chunk * 8) * 2u;
   } else {
     constexpr int LPR = W / 8, RPS = 64 / LPR;  // lanes per k-row, k-rows per 1-KiB slab
     const int krow = slab * RPS + lane / LPR;
-    const int h = (krow & 3) | (((krow >> 3) & 1) << 2);
-    const int chunk = (lane % LPR) ^ (h << 1);
+    const int chunk = (lane % LPR) ^ swz_krow(krow);
     return (unsigned)(krow * ld + chunk * 8) * 2u;
   }
+}
+
+// Two LDS-DMA instructions (16 B per lane, 1 KiB per wave-instruction) into consecutive 1-KiB slabs at LDS byte
+// address `lds`.  Inline asm on purpose: hipcc's waitcnt pass treats a builtin LDS-DMA as a pending LDS write and
+// guards later ds_reads with `s_waitcnt vmcnt(0)` whenever it cannot prove the buffers distinct -- which serialises
+// the ring (observed: every K-step of some instantiations, every tile boundary of all).  Hidden in asm, the DMA is
+// ordered by this kernel's own counted vmcnt + barrier (advance()); hipcc's counts for its own loads/stores stay
+// safe because they can only be stricter with extra operations in the queue.  M0 (the DMA's LDS base) is saved and
+// restored around the statement; the padding covers SGPR-write -> VMEM-read and M0-write -> LDS-DMA wait states
+// (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void dma2_uniform(const char* ubase, unsigned off0, unsigned off1, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 2\n\t"
+      "global_load_lds_dwordx4 %3, %2\n\t"
+      "s_add_u32 m0, %1, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %4, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds), "s"(ubase), "v"(off0), "v"(off1)
+      : "memory", "scc");
+}
+__device__ __forceinline__ void dma2_perlane(const void* p0, const void* p1, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 2\n\t"
+      "global_load_lds_dwordx4 %2, off\n\t"
+      "s_add_u32 m0, %1, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds), "v"(p0), "v"(p1)
+      : "memory", "scc");
 }
 
 template <bool KM, int W, int NWAVES>
 __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, int group, int skip,
                                            char* lds_tile, int wave, int lane) {
   constexpr int CNT = (W / 8) / NWAVES;
+  static_assert(CNT % 2 == 0, "slabs are issued in pairs");
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(lds_tile) + (unsigned)(wave * CNT) * 1024u;
   if (KM && group > 0) {   // row-remapped reduction index (patch-embed wgrad): per-lane physical rows, generic path
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) {
-      constexpr int LPR = W / 8, RPS = 64 / LPR;
-      const int slab = wave * CNT + i;
-      const int krow = slab * RPS + lane / LPR;
-      const int h = (krow & 3) | (((krow >> 3) & 1) << 2);
-      const int chunk = (lane % LPR) ^ (h << 1);
-      const __bf16* src = org + (size_t)phys_row(k0 + krow, group, skip) * ld + chunk * 8;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + slab * 1024), 16, 0, 0);
+    for (int i = 0; i < CNT; i += 2) {
+      const __bf16* src[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        constexpr int LPR = W / 8, RPS = 64 / LPR;
+        const int slab = wave * CNT + i + e;
+        const int krow = slab * RPS + lane / LPR;
+        const int chunk = (lane % LPR) ^ swz_krow(krow);
+        src[e] = org + (size_t)phys_row(k0 + krow, group, skip) * ld + chunk * 8;
+      }
+      dma2_perlane(src[0], src[1], lds0 + i * 1024u);
     }
     return;
   }
   const char* ubase = (const char*)org + (size_t)k0 * (KM ? (size_t)ld : (size_t)1) * 2;   // wave-uniform
 #pragma unroll
-  for (int i = 0; i < CNT; ++i) {
-    const int slab = wave * CNT + i;
-    const unsigned off = lane_offset<KM, W, NWAVES>(ld, wave, lane, i);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(ubase + off), LDS_PTR(lds_tile + slab * 1024), 16, 0, 0);
-  }
+  for (int i = 0; i < CNT; i += 2)
+    dma2_uniform(ubase, lane_offset<KM, W, NWAVES>(ld, wave, lane, i), lane_offset<KM, W, NWAVES>(ld, wave, lane, i + 1),
+                 lds0 + i * 1024u);
 }
 
-// One MFMA operand fragment (16 rows/cols starting at t16 of the W-wide tile, k-step kk of 2).
-template <bool KM, int W>
-__device__ __forceinline__ bf16x8 read_frag(const char* tile, int t16, int kk, int lane) {
+// Offset, inside a 64-wide wave tile, of operand row p (0..15) of 16-row tile j.  PAIRED interleaves tiles 2q and
+// 2q+1 in groups of four so that, with the operand on the MFMA's row side, lane group g = lane>>4 (which receives
+// rows 4g..4g+3 of every tile) ends up with EIGHT consecutive columns of the output per tile pair: one 16-byte bf16
+// store.  The natural order gives four consecutive columns per tile: one 16-byte fp32 store.
+template <bool PAIRED>
+__device__ __forceinline__ int tile_row(int j, int p) {
+  return PAIRED ? 32 * (j >> 1) + 8 * (p >> 2) + 4 * (j & 1) + (p & 3) : 16 * j + p;
+}
+
+// One MFMA operand fragment: 16-row tile j of the wave's operand rows starting at `base` of the W-wide LDS tile,
+// k-step kk of 2.
+template <bool KM, int W, bool PAIRED>
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int base, int j, int kk, int lane) {
   if (!KM) {
-    const int row = t16 + (lane & 15);
+    const int row = base + tile_row<PAIRED>(j, lane & 15);
 #ifdef DEVIT_GEMM_NOSWZ
     const int chunk = (kk * 4 + (lane >> 4));
 #else
-    const int chunk = (kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+    const int chunk = (kk * 4 + (lane >> 4)) ^ swz_row(row);
 #endif
     return *(const bf16x8*)(tile + row * 128 + chunk * 16);
   } else {
     const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int h = q | ((G & 1) << 2);
-    const int chunk = ((t16 >> 3) + (p >> 1)) ^ (h << 1);
+    const int col0 = base + tile_row<PAIRED>(j, 4 * p);   // this lane addresses operand rows 4p..4p+3 of k-row q
     const int krow = kk * 32 + G * 8 + q;
-    const char* a = tile + krow * (W * 2) + chunk * 16 + (p & 1) * 8;
+    const int chunk = (col0 >> 3) ^ swz_krow(krow);
+    const char* a = tile + krow * (W * 2) + chunk * 16 + ((col0 >> 2) & 1) * 8;
     return cat8(lds_tr_read(a), lds_tr_read(a + 4 * (W * 2)));
   }
 }
-
-#ifdef DEVIT_GEMM_STAMPS
-// Diagnostic build only (tools/build_stamps.sh): per-wave cycle totals of the K-loop segments.
-__device__ unsigned long long devit_gemm_stamps[8];
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define STAMP(v) const unsigned long long v = stamp()
-#else
-#define STAMP(v)
-#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// One 64x64 fp32 staging tile (this wave's) -> fused epilogue -> global memory.  Rows are processed in chunks of
-// CH iterations, each chunk in two phases so that no load waits behind the stores of an earlier row (vmcnt counts
-// loads and stores in order on gfx950): first the chunk's global inputs (residual / saved pre-activation /
-// pos-embed rows) are fetched into registers, then its rows are computed and stored back-to-back.  The chunk loop
-// stays rolled: the epilogue runs once per tile, so its code size is instruction-cache misses.
-// bf16 outputs: 8 columns (16 B) per lane; fp32: 4 columns (16 B).
-template <int KIND>
-__device__ __forceinline__ void epilogue_pass(const devit_epilogue& ep, const float* cw, int lane, int mw, int nw,
-                                              int m_lim, size_t ob) {
-  constexpr bool BF16_OUT = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
-  constexpr int COLS = BF16_OUT ? 8 : 4, LPR = 64 / COLS, RPI = 64 / LPR, ITERS = 64 / RPI, NV = COLS / 4, CH = 4;
-  const int col = (lane % LPR) * COLS, rl = lane / LPR;
-  const int n = nw + col;
-  f32x4 bias[NV], cs[NV];
+// Fused epilogue straight from the accumulators.  The K loop runs the MFMAs with the weight operand on the row side,
+// so lane (g = lane>>4, c = lane&15) holds, for m-tile i and n-tile j, C[m = 16 i + c][n = tile_row(j, 4g + r)],
+// r = 0..3: consecutive output columns in consecutive registers.  Every global access is 16 bytes per lane (8 for the
+// optional bf16 copy of the RESIDUAL kind) and the four lane groups of a row cover 64 contiguous bytes.  Rows are
+// handled two m-tiles at a time in two phases -- the chunk's global inputs (residual / saved pre-activation /
+// pos-embed) first, then compute + stores -- so that no load queues behind the stores of an earlier row (vmcnt counts
+// loads and stores in order on gfx950).  No LDS is touched: the operand ring is free while the epilogue runs.
+// FULL = every row of the tile is a real row (m < m_lim): no predicates.
+__device__ __forceinline__ bf16x8 pack8(const float (&x)[8]) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 p[4];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    bias[v] = ep.bias ? *(const f32x4*)(ep.bias + n + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    cs[v] = ep.colscale ? *(const f32x4*)(ep.colscale + n + v * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+  for (int e = 0; e < 4; ++e) p[e] = __builtin_convertvector((f32x2){x[2 * e], x[2 * e + 1]}, bf16x2);   // v_cvt_pk_bf16_f32
+  return (bf16x8){p[0][0], p[0][1], p[1][0], p[1][1], p[2][0], p[2][1], p[3][0], p[3][1]};
+}
+
+// Lanes c and c^8 of each 16-lane row trade one 16-byte chunk so that the two stores of an m-tile each write whole
+// 128-byte rows: on entry lane (g, c) holds row c's bytes [16g, 16g+16) in `a` and [64+16g, 64+16g+16) in `b`; on exit
+// `a` belongs to row (c & 7) and `b` to row 8 + (c & 7), both at byte (c >= 8 ? 64 : 0) + 16g.
+__device__ __forceinline__ void swap_half_rows(bf16x8& a, bf16x8& b, bool hi) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+  u32x4 recv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned send = hi ? ua[e] : ub[e];
+    recv[e] = __builtin_amdgcn_update_dpp(0u, send, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
   }
-#pragma unroll 1
-  for (int c0 = 0; c0 < ITERS; c0 += CH) {
-    // ---- phase 1: global inputs of the chunk
-    f32x4 gin[CH];
-    float rsc[CH];
-    bf16x8 pre[CH];
-    size_t offs[CH];
+  u32x4 oa, obb;
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int m = mw + (c0 + u) * RPI + rl;
-      const bool ok = m < m_lim;
-      size_t o = ob + (size_t)m * ep.ldc + n;
+  for (int e = 0; e < 4; ++e) {
+    oa[e] = hi ? recv[e] : ua[e];
+    obb[e] = hi ? ub[e] : recv[e];
+  }
+  a = __builtin_bit_cast(bf16x8, oa);
+  b = __builtin_bit_cast(bf16x8, obb);
+}
+
+// Per-lane column data of an epilogue: the lane's four column offsets (one per n-tile) and bias / column scale there.
+template <int KIND>
+__device__ __forceinline__ void load_cols(const devit_epilogue& ep, int lane, int nw, int (&noff)[4], f32x4 (&bias)[4],
+                                          f32x4 (&cs)[4]) {
+  constexpr bool BF16_OUT = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
+  constexpr bool SCALED = KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    noff[j] = nw + tile_row<BF16_OUT>(j, 4 * (lane >> 4));
+    bias[j] = ep.bias ? *(const f32x4*)(ep.bias + noff[j]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (SCALED) cs[j] = ep.colscale ? *(const f32x4*)(ep.colscale + noff[j]) : (f32x4){1.f, 1.f, 1.f, 1.f};
+  }
+}
+// Make hipcc wait for the loads of load_cols() HERE (an empty asm that reads them).  Its waitcnt pass does not see
+// the asm LDS-DMA: a wait it places after the next DMA issue would also wait for that DMA.
+template <int KIND>
+__device__ __forceinline__ void settle_cols(f32x4 (&bias)[4], f32x4 (&cs)[4]) {
+  constexpr bool SCALED = KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    asm volatile("" : "+v"(bias[j]));
+    if (SCALED) asm volatile("" : "+v"(cs[j]));
+  }
+}
+
+template <int KIND, int MI, bool FULL>
+__device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 (&acc)[MI][4], const int (&noff)[4],
+                                                const f32x4 (&bias)[4], const f32x4 (&cs)[4], int lane, int mw,
+                                                int m_lim, size_t ob) {
+  constexpr bool BF16_OUT = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
+  constexpr int CHI = 2;
+  const int c = lane & 15;
+#pragma unroll
+  for (int i0 = 0; i0 < MI; i0 += CHI) {
+    // ---- phase 1: global inputs of the chunk
+    f32x4 gin[CHI][4];
+    float rsc[CHI];
+    bf16x8 pre[CHI][2];
+    size_t rowo[CHI];
+#pragma unroll
+    for (int u = 0; u < CHI; ++u) {
+      const int m = mw + (i0 + u) * 16 + c;
+      const bool ok = FULL || m < m_lim;
+      size_t o = ob + (size_t)m * ep.ldc;
       if (KIND == DEVIT_EPI_PATCH_F32) {
         const int b = m / ep.patch_tokens, t = m - b * ep.patch_tokens, tok = ep.extra_tokens + t;
-        o = ((size_t)b * (ep.patch_tokens + ep.extra_tokens) + tok) * ep.ldc + n;
-        gin[u] = ok ? *(const f32x4*)(ep.pos + (size_t)tok * ep.ldc + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        o = ((size_t)b * (ep.patch_tokens + ep.extra_tokens) + tok) * ep.ldc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          gin[u][j] = ok ? *(const f32x4*)(ep.pos + (size_t)tok * ep.ldc + noff[j]) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
       if (KIND == DEVIT_EPI_RESIDUAL_F32) {
-        gin[u] = ok ? load_stream((const f32x4*)(ep.res + o)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          gin[u][j] = ok ? load_stream((const f32x4*)(ep.res + o + noff[j])) : (f32x4){0.f, 0.f, 0.f, 0.f};
         rsc[u] = (ok && ep.rowscale) ? ep.rowscale[m / ep.rows_per_scale] : 1.0f;
       }
       if (KIND == DEVIT_EPI_DGELU_BF16) {
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        pre[u] = ok ? load_stream((const bf16x8*)((const __bf16*)ep.aux_in + o)) : z;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          pre[u][q] = ok ? load_stream((const bf16x8*)((const __bf16*)ep.aux_in + o + noff[2 * q])) : z;
       }
-      offs[u] = o;
+      rowo[u] = o;
     }
     // ---- phase 2: compute + store
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int row = (c0 + u) * RPI + rl;
-      const bool ok = mw + row < m_lim;
-      const size_t o = offs[u];
-      f32x4 v[NV];
+    for (int u = 0; u < CHI; ++u) {
+      const int i = i0 + u;
+      const bool ok = FULL || mw + i * 16 + c < m_lim;
+      const size_t o = rowo[u];
+      if constexpr (!BF16_OUT) {
 #pragma unroll
-      for (int w = 0; w < NV; ++w) v[w] = *(const f32x4*)(cw + row * 64 + col + w * 4) + bias[w];
-      if (KIND == DEVIT_EPI_STORE_F32) {
-        if (ok) *(f32x4*)((float*)ep.out + o) = v[0];
-      } else if (KIND == DEVIT_EPI_PATCH_F32) {
-        if (ok) *(f32x4*)((float*)ep.out + o) = v[0] + gin[u];
-      } else if (KIND == DEVIT_EPI_RESIDUAL_F32) {
-        if (ok) {
-          if (ep.aux) {
-            const bf16x4 pb = {f2bf(v[0][0]), f2bf(v[0][1]), f2bf(v[0][2]), f2bf(v[0][3])};
-            *(bf16x4*)((__bf16*)ep.aux + o) = pb;
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 v = acc[i][j] + bias[j];
+          if (KIND == DEVIT_EPI_STORE_F32) {
+            if (ok) *(f32x4*)((float*)ep.out + o + noff[j]) = v;
+          } else if (KIND == DEVIT_EPI_PATCH_F32) {
+            if (ok) *(f32x4*)((float*)ep.out + o + noff[j]) = v + gin[u][j];
+          } else {  // RESIDUAL_F32
+            if (ok) {
+              if (ep.aux) {
+                const bf16x4 pb = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *(bf16x4*)((__bf16*)ep.aux + o + noff[j]) = pb;
+              }
+              *(f32x4*)((float*)ep.out + o + noff[j]) = gin[u][j] + rsc[u] * v;
+            }
           }
-          *(f32x4*)((float*)ep.out + o) = gin[u] + rsc[u] * v[0];
         }
       } else {
-        float x[8];
+        bf16x8 outc[2], prec[2];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = v[c >> 2][c & 3];
-        if (KIND == DEVIT_EPI_GELU_BF16) {
-          if (ok && ep.aux) {
-            const bf16x8 pb = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(x[4]), f2bf(x[5]), f2bf(x[6]), f2bf(x[7])};
-            *(bf16x8*)((__bf16*)ep.aux + o) = pb;
+        for (int q = 0; q < 2; ++q) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = acc[i][2 * q + (e >> 2)][e & 3] + bias[2 * q + (e >> 2)][e & 3];
+          if (KIND == DEVIT_EPI_GELU_BF16) {
+            prec[q] = pack8(x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = gelu_fwd<false>(x[e]) * cs[2 * q + (e >> 2)][e & 3];
+          } else if (KIND == DEVIT_EPI_DGELU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = x[e] * cs[2 * q + (e >> 2)][e & 3] * gelu_bwd<false>(bf2f(pre[u][q][e]));
           }
-#pragma unroll
-          for (int c = 0; c < 8; ++c) x[c] = gelu_fwd<false>(x[c]) * cs[c >> 2][c & 3];
-        } else if (KIND == DEVIT_EPI_DGELU_BF16) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) x[c] = x[c] * cs[c >> 2][c & 3] * gelu_bwd<false>(bf2f(pre[u][c]));
+          outc[q] = pack8(x);
         }
-        if (ok) {
-          const bf16x8 ob8 = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(x[4]), f2bf(x[5]), f2bf(x[6]), f2bf(x[7])};
-          *(bf16x8*)((__bf16*)ep.out + o) = ob8;
+        // whole 128-byte rows per store: rows (c & 7) and 8 + (c & 7) of this m-tile, see swap_half_rows()
+        const bool hi = c >= 8;
+        const int mA = mw + i * 16 + (c & 7);
+        const size_t oA = ob + (size_t)mA * ep.ldc + noff[0] + (hi ? 32 : 0), oB = oA + (size_t)8 * ep.ldc;
+        const bool okA = FULL || mA < m_lim, okB = FULL || mA + 8 < m_lim;
+        swap_half_rows(outc[0], outc[1], hi);
+        if (KIND == DEVIT_EPI_GELU_BF16 && ep.aux) {
+          swap_half_rows(prec[0], prec[1], hi);
+          if (okA) *(bf16x8*)((__bf16*)ep.aux + oA) = prec[0];
+          if (okB) *(bf16x8*)((__bf16*)ep.aux + oB) = prec[1];
         }
+        if (okA) *(bf16x8*)((__bf16*)ep.out + oA) = outc[0];
+        if (okB) *(bf16x8*)((__bf16*)ep.out + oB) = outc[1];
       }
     }
   }
 }
 
-// BM x BN x 64 tile, WAVES_M x WAVES_N waves (each (BM/WAVES_M) x (BN/WAVES_N)), NSTAGE-deep LDS ring filled
-// by LDS-DMA.  One raw barrier per K-step; the DMA of the NSTAGE-2 newest stages stays in flight across it
-// (counted vmcnt), cdna_hip_programming.md "Pipelining across barriers".
+// Where one output tile's operands start and which K-steps it covers (all wave-uniform).
+struct TileRef {
+  const __bf16* a;
+  const __bf16* b;
+  int m0, n0, bz, kt0, nk;
+};
+
+template <int BM, int BN, bool A_KM, bool B_KM>
+__device__ __forceinline__ TileRef decode_tile(const GemmArgs& g, int w) {
+  const int zz = fdiv(w, g.d_per_z);
+  const int r0 = w - zz * g.d_per_z.d;
+  const int chunk = fdiv(r0, g.d_chunk);                // full chunks (gn n-tiles x all m-tiles) come first
+  const int r1 = r0 - chunk * g.d_chunk.d;
+  const bool lastc = (chunk + 1) * g.gn > g.tiles_n;    // the last chunk may be narrower
+  const int tm = lastc ? fdiv(r1, g.d_last) : fdiv(r1, g.d_gn);
+  const int tn = chunk * g.gn + r1 - tm * (lastc ? g.d_last.d : g.d_gn.d);
+  const int bzq = fdiv(zz, g.d_split);
+  const int z = zz - bzq * g.split_k, nk_total = g.K / BK;
+  TileRef t;
+  t.bz = bzq;
+  t.m0 = tm * BM;
+  t.n0 = tn * BN;
+  t.kt0 = fdiv(z * nk_total, g.d_split);
+  t.nk = fdiv((z + 1) * nk_total, g.d_split) - t.kt0;
+  t.a = g.A + (size_t)t.bz * g.a_bs + (A_KM ? (size_t)t.m0 : (size_t)t.m0 * g.lda);
+  t.b = g.B + (size_t)t.bz * g.b_bs + (B_KM ? (size_t)t.n0 : (size_t)t.n0 * g.ldb);
+  return t;
+}
+
+// Persistent BM x BN x 64 GEMM: WAVES_M x WAVES_N waves (each (BM/WAVES_M) x (BN/WAVES_N)), NSTAGE-deep LDS ring
+// filled by LDS-DMA.  A workgroup walks its share of the output tiles and treats their K-steps as ONE stream of ring
+// stages: the refill issued during the last K-steps of a tile already belongs to the next tile, so neither the
+// DMA latency of a tile's first stages nor the register-only epilogue leaves the ring empty.  One raw barrier per
+// K-step; the DMA of the newest stages stays in flight across it (counted vmcnt -- the count names the DMA
+// instructions issued after the stage being waited for; epilogue stores queued in between only make the wait
+// stricter, never unsafe, because vmcnt retires in order).
+// Tile order: workgroups b, b+8, ... share an XCD (and its L2); each XCD owns a contiguous run of tiles (n-tile
+// fastest inside an L2-sized chunk of B, see decode_tile) and its workgroups walk that run side by side.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool A_KM, bool B_KM, int KIND>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
   static_assert(WN == 64 && WM % 64 == 0, "wave tile must be (64 k) x 64");
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+  // Every epilogue but the split-K atomic one runs straight from the accumulators: the MFMAs then take the B operand
+  // (output columns) on their row side, see epilogue_direct().  The atomic one stages through the ring's LDS, so its
+  // stream stops at every tile end.
+  constexpr bool DIRECT = KIND != DEVIT_EPI_ATOMIC_F32;
+  constexpr bool PAIRED = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
   constexpr int A_TILE_BYTES = BM * BK * 2, B_TILE_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
   constexpr int PER = (BM / 8 + BN / 8) / NWAVES;  // LDS-DMA instructions per wave per stage
@@ -233,158 +410,137 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
-  // contiguous run of tiles, n-tile fastest, so one A row-panel is fetched from HBM once per XCD.
-  const int nwg = gridDim.x;
-  int w = blockIdx.x;
+  // this workgroup's tiles: first, first + stride, ... < last
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  int first, last;
   {
-    const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
-    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int q = g.total_tiles >> 3, r = g.total_tiles & 7;
+    const int start = xcd * q + min(xcd, r);
+    first = start + idx;
+    last = start + q + (xcd < r ? 1 : 0);
   }
-  const int per_z = g.tiles_n * g.tiles_m;
-  const int zz = w / per_z;
-  int tm, tn;
-  {
-    const int r0 = w - zz * per_z;
-    const int chunk = r0 / (g.gn * g.tiles_m);          // full chunks come first
-    const int r1 = r0 - chunk * g.gn * g.tiles_m;
-    const int width = min(g.gn, g.tiles_n - chunk * g.gn);
-    tm = r1 / width;
-    tn = chunk * g.gn + r1 % width;
-  }
-  const int z = zz % g.split_k, bz = zz / g.split_k;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nk_total = g.K / BK;
-  const int kt0 = z * nk_total / g.split_k;
-  const int kt1 = (z + 1) * nk_total / g.split_k;
-  const int nk = kt1 - kt0;
+  if (first >= last) return;
 
-  const __bf16* a_org = g.A + (size_t)bz * g.a_bs + (A_KM ? (size_t)m0 : (size_t)m0 * g.lda);
-  const __bf16* b_org = g.B + (size_t)bz * g.b_bs + (B_KM ? (size_t)n0 : (size_t)n0 * g.ldb);
-
-#ifdef DEVIT_GEMM_STAMPS
-  const unsigned long long k_entry = stamp();
-#endif
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  auto stage = [&](int t) {
-    char* buf = smem + (t % NSTAGE) * STAGE_BYTES;
-    stage_tile<A_KM, BM, NWAVES>(a_org, g.lda, (kt0 + t) * BK, g.a_group, g.a_skip, buf, wave, lane);
-    stage_tile<B_KM, BN, NWAVES>(b_org, g.ldb, (kt0 + t) * BK, g.b_group, g.b_skip, buf + A_TILE_BYTES, wave, lane);
+  // producer cursor: the next ring stage to request
+  TileRef pt = decode_tile<BM, BN, A_KM, B_KM>(g, first);
+  int p_tile = first, p_t = 0, p_slot = 0, inflight = 0;
+  bool p_open = true;                                   // false: nothing (more) to request right now
+  auto produce = [&]() {
+    char* buf = smem + p_slot * STAGE_BYTES;
+    stage_tile<A_KM, BM, NWAVES>(pt.a, g.lda, (pt.kt0 + p_t) * BK, g.a_group, g.a_skip, buf, wave, lane);
+    stage_tile<B_KM, BN, NWAVES>(pt.b, g.ldb, (pt.kt0 + p_t) * BK, g.b_group, g.b_skip, buf + A_TILE_BYTES, wave, lane);
+    p_slot = p_slot + 1 == NSTAGE ? 0 : p_slot + 1;
+    ++inflight;
+    if (++p_t == pt.nk) {
+      p_t = 0;
+      p_tile += stride;
+      if (DIRECT && p_tile < last) pt = decode_tile<BM, BN, A_KM, B_KM>(g, p_tile);
+      else p_open = false;
+    }
   };
-
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nk) stage(s);
+    if (p_open) produce();
 
-#ifdef DEVIT_GEMM_STAMPS
-  unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
-  const unsigned long long k_loop0 = stamp();
-#endif
-  for (int t = 0; t < nk; ++t) {
-    STAMP(s0);
-    // stage t must have landed; the NSTAGE-2 stages issued after it may stay in flight
-    if (t + NSTAGE - 2 < nk) wait_vmcnt<PER * (NSTAGE - 2)>();
+  // Make the oldest stage in flight readable: it must have landed (the ones requested after it may stay in flight),
+  // every wave must know so and must have finished reading the slot the refill overwrites (the one read a step ago).
+  auto advance = [&]() {
+    if (NSTAGE == 3 && inflight == 2) wait_vmcnt<PER>();
     else wait_vmcnt<0>();
-    STAMP(s1);
-    __builtin_amdgcn_s_barrier();  // everyone's stage-t DMA landed; everyone finished reading stage t-1
-    STAMP(s2);
-#ifndef DEVIT_GEMM_DMA_MID
-    if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1);  // overwrites the buffer read at step t-1
-#endif
-    STAMP(s3);
-    const char* cur = smem + (t % NSTAGE) * STAGE_BYTES;
-#ifdef DEVIT_GEMM_NOCOMPUTE
-    if (g.K < 0)
-#endif
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#ifdef DEVIT_GEMM_DMA_MID
-      if (kk == 1) {   // issue the refill between the two MFMA bursts: the SIMD's other wave is usually mid-burst
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
-      bf16x8 af[MI], bfr[NI];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN>(cur + A_TILE_BYTES, wn * WN + j * 16, kk, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM>(cur, wm * WM + i * 16, kk, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
-    }
-#ifdef DEVIT_GEMM_STAMPS
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // let the last MFMAs drain before the stamp
-    STAMP(s4);
-    c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
-#endif
-  }
-#ifdef DEVIT_GEMM_STAMPS
-  const unsigned long long k_loop1 = stamp();
-  if (lane == 0) {
-    atomicAdd(&devit_gemm_stamps[0], c_wait); atomicAdd(&devit_gemm_stamps[1], c_bar);
-    atomicAdd(&devit_gemm_stamps[2], c_issue); atomicAdd(&devit_gemm_stamps[3], c_comp);
-    atomicAdd(&devit_gemm_stamps[4], k_loop0 - k_entry); atomicAdd(&devit_gemm_stamps[5], k_loop1 - k_loop0);
-  }
-#endif
-  __syncthreads();  // all fragment reads done before the ring is reused as the epilogue staging area
-
-  // ---- epilogue: accumulators -> this wave's private 64x64 f32 LDS tile -> row-wise global I/O,
-  //      one pass per 64 rows of the wave tile
-  float* cw = (float*)smem + wave * 4096;
-  const devit_epilogue& ep = g.ep;
-  const size_t ob = (size_t)bz * ep.out_batch_stride;
-  const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
-  const int nw = n0 + wn * WN;
-  auto do_pass = [&](auto pass_c) {
-    constexpr int pass = decltype(pass_c)::value;
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cw[(i * 16 + (lane >> 4) * 4 + r) * 64 + j * 16 + (lane & 15)] = acc[pass * 4 + i][j][r];
-  // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
-  const int mw = m0 + wm * WM + pass * 64;
-
-  if constexpr (KIND == DEVIT_EPI_ATOMIC_F32) {
-    float* out = (float*)ep.out + ob;
-    for (int row = 0; row < 64; ++row) {
-      const float v = cw[row * 64 + lane];
-      if (mw + row < m_lim) unsafeAtomicAdd(out + (size_t)(mw + row) * ep.ldc + nw + lane, v);
-    }
-  } else {
-    epilogue_pass<KIND>(ep, cw, lane, mw, nw, m_lim, ob);
-  }
+    __builtin_amdgcn_s_barrier();
+    if (p_open) produce();
+    --inflight;
   };
-  do_pass(std::integral_constant<int, 0>());
-  if constexpr (MI > 4) do_pass(std::integral_constant<int, 1>());
 
-#ifdef DEVIT_GEMM_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned long long k_end = stamp();
-  if (lane == 0) atomicAdd(&devit_gemm_stamps[6], k_end - k_loop1);
-#endif
-}
+  int c_slot = 0;
+  bool primed = false;   // the stage at c_slot is already readable (advance() ran for it before the last epilogue)
+  for (int tile = first; tile < last; tile += stride) {
+    const TileRef ct = decode_tile<BM, BN, A_KM, B_KM>(g, tile);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#ifdef DEVIT_GEMM_STAMPS
-}  // namespace
-extern "C" int devit_debug_gemm_stamps(unsigned long long* out4, int reset) {
-  hipMemcpyFromSymbol(out4, HIP_SYMBOL(devit_gemm_stamps), 64);
-  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(devit_gemm_stamps), z, 64); }
-  return 0;
+    auto kstep = [&]() {
+      const char* cur = smem + c_slot * STAGE_BYTES;
+      c_slot = c_slot + 1 == NSTAGE ? 0 : c_slot + 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[MI], bfr[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN, PAIRED>(cur + A_TILE_BYTES, wn * WN, j, kk, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM, false>(cur, wm * WM, i, kk, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = DIRECT ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+      }
+    };
+    const devit_epilogue& ep = g.ep;
+    const int nw = ct.n0 + wn * WN;
+    for (int t = 0; t < ct.nk - 1; ++t) {
+      if (t > 0 || !primed) advance();
+      kstep();
+    }
+    // last K-step of the tile: the epilogue's column data (bias, column scale) is fetched under its MFMAs
+    if (ct.nk > 1 || !primed) advance();
+    int noff[4];
+    f32x4 bias[4], cs[4];
+    if constexpr (DIRECT) load_cols<KIND>(ep, lane, nw, noff, bias, cs);
+    kstep();
+    if constexpr (DIRECT) settle_cols<KIND>(bias, cs);
+    // The next tile's first stage is made readable BEFORE this tile's epilogue: a wait placed after the epilogue
+    // would also wait for its stores (vmcnt retires in order), which a finishing workgroup never has to do.
+    primed = DIRECT && tile + stride < last;
+    if (primed) advance();
+
+    const size_t ob = (size_t)ct.bz * ep.out_batch_stride;
+    const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
+    if constexpr (DIRECT) {
+      // FULL: no row of the tile is padding -> straight-line code without per-row predicates (the predicated form makes
+      // hipcc wait vmcnt(0) in front of every chunk: it cannot count stores across the skipped branches)
+      if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+      else epilogue_direct<KIND, MI, false>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+    } else {
+      // split-K partial sums: accumulators -> this wave's private 64x64 f32 LDS tile -> one atomic per element, 64
+      // consecutive floats per instruction; one pass per 64 rows of the wave tile.  The ring is empty here
+      // (inflight == 0: the stream stops at tile ends for this kind).
+      __syncthreads();  // all fragment reads done before the ring is reused as the staging area
+      float* cw = (float*)smem + wave * 4096;
+      float* out = (float*)ep.out + ob;
+      auto do_pass = [&](auto pass_c) {
+        constexpr int pass = decltype(pass_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              cw[(i * 16 + (lane >> 4) * 4 + r) * 64 + j * 16 + (lane & 15)] = acc[pass * 4 + i][j][r];
+        // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
+        const int mw = ct.m0 + wm * WM + pass * 64;
+        for (int row = 0; row < 64; ++row) {
+          const float v = cw[row * 64 + lane];
+          if (mw + row < m_lim) unsafeAtomicAdd(out + (size_t)(mw + row) * ep.ldc + nw + lane, v);
+        }
+      };
+      do_pass(std::integral_constant<int, 0>());
+      if constexpr (MI > 4) do_pass(std::integral_constant<int, 1>());
+      if (p_tile < last) {           // restart the stream on the next tile
+        __syncthreads();             // every wave's staging reads done before the DMA overwrites them
+        pt = decode_tile<BM, BN, A_KM, B_KM>(g, p_tile);
+        p_open = true;
+        p_slot = c_slot;
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s)
+          if (p_open) produce();
+      }
+    }
+  }
 }
-namespace {
-#endif
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -454,13 +610,33 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   g.tiles_m = M / bm;
   g.tiles_n = N / bn;
   if (g.gn > g.tiles_n) g.gn = g.tiles_n;
-  const long long nwg = (long long)g.tiles_m * g.tiles_n * split_k * batch;
-  DEVIT_CHECK(nwg < (1ll << 31), DEVIT_ERR_SHAPE, "devit_gemm_bf16: grid too large");
+  const long long tiles = (long long)g.tiles_m * g.tiles_n * split_k * batch;
+  DEVIT_CHECK(tiles < (1ll << 31), DEVIT_ERR_SHAPE, "devit_gemm_bf16: too many tiles");
+  g.total_tiles = (int)tiles;
+  g.d_per_z = make_fastdiv(g.tiles_m * g.tiles_n);
+  g.d_chunk = make_fastdiv(g.gn * g.tiles_m);
+  g.d_gn = make_fastdiv(g.gn);
+  g.d_last = make_fastdiv(g.tiles_n % g.gn ? g.tiles_n % g.gn : g.gn);
+  g.d_split = make_fastdiv(split_k);
+  // persistent grid: as many workgroups as stay resident (LDS: two 128x128 rings or one 256-wide ring per CU), a
+  // multiple of 8 so that every XCD gets the same number
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    DEVIT_CHECK(hipGetDevice(&dev) == hipSuccess &&
+                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8,
+                DEVIT_ERR_DEVICE, "devit_gemm_bf16: cannot query the CU count");
+    cus = n;
+  }
+  static const int occ_env = getenv("DEVIT_GEMM_OCC") ? atoi(getenv("DEVIT_GEMM_OCC")) : 0;
+  const int occ = occ_env > 0 ? occ_env : (cfg == 1 ? 2 : 1);
+  long long nwg = ((long long)cus * occ) / 8 * 8;
+  if (nwg > (tiles + 7) / 8 * 8) nwg = (tiles + 7) / 8 * 8;
   hipStream_t s = (hipStream_t)stream;
 #define DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_)                                          \
   do {                                                                                                         \
     constexpr int ring = NS_ * (BM_ + BN_) * 128, stagebytes = WMM_ * WNN_ * 16384;                            \
-    constexpr int lds = ring > stagebytes ? ring : stagebytes;                                                 \
+    constexpr int lds = (KIND_ == DEVIT_EPI_ATOMIC_F32 && stagebytes > ring) ? stagebytes : ring;              \
     static bool attr = false;                                                                                  \
     if (!attr) {                                                                                               \
       hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_>, \
