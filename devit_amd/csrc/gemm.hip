@@ -606,6 +606,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   static const int wg_cfg = getenv("DEVIT_GEMM_WGRAD_TILE") ? atoi(getenv("DEVIT_GEMM_WGRAD_TILE")) : 0;
   if (variant == 3 && wg_cfg > 0) cfg = wg_cfg;
   if (force > 0 && force < cfg) cfg = force;
+  static const int exact = getenv("DEVIT_GEMM_FORCE") ? atoi(getenv("DEVIT_GEMM_FORCE")) : 0;   // experiments
+  if (exact == 1 || (exact == 2 && M % 256 == 0) || (exact == 3 && M % 256 == 0 && N % 256 == 0 && variant != 3)) cfg = exact;
   const int bm = cfg == 1 ? 128 : 256, bn = cfg == 3 ? 256 : 128;
   g.tiles_m = M / bm;
   g.tiles_n = N / bn;

@@ -167,23 +167,27 @@ class DropPath(nn.Module):
         raise RuntimeError("DropPath is folded into the residual GEMM epilogue; it is never called directly")
 
 
+_keep_cache = {}
+
+
 def draw_dp_scales(blocks_params, B, device, training):
-    scales, any_dp = [], False
-    for bp in blocks_params:
-        p = bp.dp_prob if training else 0.
-        if p > 0.:
-            keep = 1.0 - p
-            u = torch.rand((2, B), dtype=torch.float32, device=device)
-            sc = torch.floor(keep + u) / keep
-            scales.append((sc[0].contiguous(), sc[1].contiguous()))
-            any_dp = True
-        else:
-            scales.append(None)
-    return scales if any_dp else None
+    """Per-sample stochastic-depth scales floor(keep + u) / keep (models/de_vit.py:114-121, timm DropPath) for both
+    branches of every block, drawn with ONE rand call per forward."""
+    probs = [bp.dp_prob if training else 0. for bp in blocks_params]
+    if not any(p > 0. for p in probs):
+        return None
+    key = (tuple(probs), str(device))
+    keep = _keep_cache.get(key)
+    if keep is None:
+        keep = torch.tensor([1.0 - p for p in probs], dtype=torch.float32, device=device).view(-1, 1, 1)
+        _keep_cache[key] = keep
+    u = torch.rand((len(probs), 2, B), dtype=torch.float32, device=device)
+    sc = torch.floor(keep + u) / keep
+    return [(sc[i, 0], sc[i, 1]) if p > 0. else None for i, p in enumerate(probs)]
 
 
 def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=None, dp_scales="draw", exact_gelu=0,
-               precision="bf16"):
+               precision="bf16", qkv_pad_layers=None):
     """Run a list of Blocks as one EncoderFn node.  Returns (x, qkv tuples, att tensors, enc tensors)."""
     L.require_device(x)
     if x.dtype != torch.float32:
@@ -193,7 +197,7 @@ def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=Non
     if dp_scales == "draw":
         dp_scales = draw_dp_scales(bps, B, x.device, training)
     cfg = ops.EncoderCfg(bps, training, dp_scales, want_qkv, want_att, want_enc, exact_gelu=exact_gelu,
-                         grad_ready=grad_ready)
+                         grad_ready=grad_ready, qkv_pad_layers=qkv_pad_layers)
     cfg.grad_enabled = torch.is_grad_enabled()
     flat = [p for bp in bps for p in bp.all_params()]
     if precision == "f32":
@@ -351,7 +355,8 @@ class VisionTransformer(nn.Module):
         emb = x
         xo, qkvs, atts, encs = run_blocks(list(self.blocks), x, self.training, output_qkv, output_att, output_encoders,
                                           grad_ready=self.grad_ready, exact_gelu=self.exact_gelu,
-                                          precision=self.precision)
+                                          precision=self.precision,
+                                          qkv_pad_layers=getattr(self, "qkv_pad_layers", None))
         depth = len(self.blocks)
         encoder_outputs = [emb] if output_emb else []
         encoder_outputs += encs if output_encoders else [None] * depth

@@ -19,6 +19,11 @@ def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3)
                     criterion=None, dp_scales="draw"):
     """One DEKD forward.  Returns dict(loss, cls_loss, q_loss, k_loss, v_loss, logits, teacher_logits)."""
     vit = model.module if hasattr(model, "module") else model
+    # only the middle block's q/k/v enter the relation loss (engine.py:91-100): the other blocks' packed qkv buffers
+    # need no zeroed overhang rows
+    for m in (vit, teacher_model):
+        if getattr(m, "qkv_pad_layers", None) is None and hasattr(m, "blocks"):
+            m.qkv_pad_layers = {len(m.blocks) // 2 - 1}
     pre_teacher = None
     if os.environ.get("DEVIT_TEACHER_STREAM", "1") == "1" and samples.is_cuda:
         pre_teacher = _teacher_forward_async(teacher_model, samples)
@@ -83,7 +88,8 @@ def _teacher_forward_async(teacher_model, samples):
 def _forward_with_dp(vit, samples, dp_scales):
     x = vit.embed(samples)
     xo, qkvs, _, _ = de_vit.run_blocks(list(vit.blocks), x, vit.training, True, False, False,
-                                       grad_ready=vit.grad_ready, dp_scales=dp_scales, precision=vit.precision)
+                                       grad_ready=vit.grad_ready, dp_scales=dp_scales, precision=vit.precision,
+                                       qkv_pad_layers=getattr(vit, "qkv_pad_layers", None))
     heads = vit._tokens_and_logits(xo, True)
     return {'output': (heads[1], heads[2]) if vit.training else (heads[1] + heads[2]) / 2, 'qkv': qkvs}
 

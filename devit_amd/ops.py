@@ -179,13 +179,15 @@ class EncoderCfg:
     """Non-tensor arguments of EncoderFn."""
 
     def __init__(self, blocks, training, dp_scales, want_qkv, want_att, want_enc, eps=1e-6, exact_gelu=0,
-                 grad_ready=None):
+                 grad_ready=None, qkv_pad_layers=None):
         self.blocks, self.training, self.dp_scales = blocks, training, dp_scales
         self.want_qkv, self.want_att, self.want_enc = want_qkv, want_att, want_enc
         self.eps, self.exact_gelu, self.grad_ready = eps, exact_gelu, grad_ready
+        # blocks whose packed qkv output gets the zeroed overhang rows RelationLossFn reads (None: every block)
+        self.qkv_pad_layers = qkv_pad_layers
 
 
-def _block_forward(x, bp, dp, cfg, need_grad, want_att):
+def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
     """x: fp32 [B, N, D] contiguous.  Returns (x_out, saved dict)."""
     B, N, D = x.shape
     M, H, dev = B * N, bp.num_heads, x.device
@@ -195,7 +197,8 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att):
     mean1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     rstd1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     layernorm_fwd(x2, M, D, bp.n1w, bp.n1b, cfg.eps, y_bf16=ln1, mean=mean1, rstd=rstd1)
-    qkv = rows_alloc(M, 3 * D, BF16, dev, extra=128)
+    # the attention kernels never read rows >= B*N; the relation-loss windows (RelationLossFn) overhang by up to 128
+    qkv = rows_alloc(M, 3 * D, BF16, dev, extra=128 if pad_qkv else 0)
     linear_fwd(ln1, bp.qkv_w16, bp.qkv_b, M, out=qkv)
     attn_o = rows_alloc(M, D, BF16, dev)
     lse = torch.empty((B, H, N), dtype=F32, device=dev) if need_grad else None
@@ -291,7 +294,8 @@ class EncoderFn(torch.autograd.Function):
         saved, qkvs, atts, encs = [], [], [], []
         for i, bp in enumerate(cfg.blocks):
             dp = cfg.dp_scales[i] if cfg.dp_scales is not None else None
-            x, qkv, att, s = _block_forward(x, bp, dp, cfg, need_grad, cfg.want_att)
+            pad = bool(cfg.want_qkv) and (cfg.qkv_pad_layers is None or i in cfg.qkv_pad_layers)
+            x, qkv, att, s = _block_forward(x, bp, dp, cfg, need_grad, cfg.want_att, pad)
             saved.append(s)
             if cfg.want_qkv:
                 qkvs.append(qkv)
@@ -501,7 +505,7 @@ class AttentionFn(torch.autograd.Function):
         M, dev, H = B * N, x.device, module.num_heads
         xb = _to_rows_bf16(x)
         need = grad_enabled and (x.requires_grad or wq.requires_grad)
-        qkv = rows_alloc(M, 3 * D, BF16, dev, extra=128)
+        qkv = rows_alloc(M, 3 * D, BF16, dev)
         linear_fwd(xb, wq16, bq, M, out=qkv)
         o = rows_alloc(M, D, BF16, dev)
         lse = torch.empty((B, H, N), dtype=F32, device=dev) if need else None

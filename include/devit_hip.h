@@ -85,7 +85,7 @@ typedef struct {
   const float* pos;        /* PATCH: [tok + T][N] f32 position embedding */
   int patch_tokens;        /* PATCH: T = 196 */
   int extra_tokens;        /* PATCH: tok = 2 (cls + dist) or 1 */
-  int exact_gelu;          /* must be 0: GELU uses an erf with |err| < 1.5e-7 (erff() variant not built) */
+  int exact_gelu;          /* must be 0: the fused GELU is a fitted form, |err| <= 2.6e-5 (erff() variant not built) */
   long long out_batch_stride; /* elements between consecutive batch outputs (out, aux, aux_in, res) */
   int m_valid;             /* > 0: rows m >= m_valid of each batch are not stored */
 } devit_epilogue;

@@ -19,3 +19,7 @@ for name, N, K, kind in (("S qkv store", 1152, 384, 0), ("S proj resid", 384, 38
 a = torch.randn(M, 384, device=dev).to(BF); w = (torch.randn(384, 1536, device=dev) * .02).to(BF); pre = torch.randn(M, 1536, device=dev).to(BF); out = torch.empty(M, 1536, dtype=BF, device=dev)
 t = timeit(lambda: ops.gemm(a, 384, 0, w, 1536, 1, M, 1536, 384, kind=4, out=out, ldc=1536, aux_in=pre))
 print(f"tile={tag:5s} {'S fc2 dgrad dgelu':16s} {2.0*M*1536*384/t/1e12:7.1f} TF {t*1e6:7.1f} us", flush=True)
+for name, N, K in (("S fc1 dgrad", 384, 1536), ("S qkv dgrad", 384, 1152), ("S proj dgrad", 384, 384)):
+    a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(K, N, device=dev) * .02).to(BF); out = torch.empty(M, N, dtype=BF, device=dev)
+    t = timeit(lambda: ops.gemm(a, K, 0, w, N, 1, M, N, K, kind=0, out=out, ldc=N))
+    print(f"tile={tag:5s} {name:16s} {2.0*M*N*K/t/1e12:7.1f} TF {t*1e6:7.1f} us", flush=True)

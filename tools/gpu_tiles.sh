@@ -1,2 +1,5 @@
+#!/bin/bash
 export TMPDIR=/tmp
-for r in 1 2; do for t in 0 1 2; do if [ $t = 0 ]; then python tools/gemm_tiles.py; else DEVIT_GEMM_TILE=$t python tools/gemm_tiles.py; fi; done; done 2>&1 | grep TF
+for i in 1 2; do
+for f in 0 1 2 3; do echo "== force$f"; DEVIT_GEMM_FORCE=$f timeout 300 python tools/gemm_tiles.py 2>&1 | grep TF; done
+done
