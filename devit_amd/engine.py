@@ -16,8 +16,9 @@ from . import de_vit, losses
 
 
 def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0,
-                    criterion=None, dp_scales="draw"):
-    """One DEKD forward.  Returns dict(loss, cls_loss, q_loss, k_loss, v_loss, logits, teacher_logits)."""
+                    criterion=None, dp_scales="draw", teacher_outputs=None):
+    """One DEKD forward.  Returns dict(loss, cls_loss, q_loss, k_loss, v_loss, logits, teacher_logits).
+    teacher_outputs: the teacher's outputs for `samples` if they were computed ahead (TeacherLookahead)."""
     vit = model.module if hasattr(model, "module") else model
     # only the middle block's q/k/v enter the relation loss (engine.py:91-100): the other blocks' packed qkv buffers
     # need no zeroed overhang rows
@@ -25,14 +26,15 @@ def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3)
         if getattr(m, "qkv_pad_layers", None) is None and hasattr(m, "blocks"):
             m.qkv_pad_layers = {len(m.blocks) // 2 - 1}
     pre_teacher = None
-    if os.environ.get("DEVIT_TEACHER_STREAM", "1") == "1" and samples.is_cuda:
+    if teacher_outputs is None and os.environ.get("DEVIT_TEACHER_STREAM", "1") == "1" and samples.is_cuda:
         pre_teacher = _teacher_forward_async(teacher_model, samples)
     if dp_scales != "draw":   # explicit DropPath masks (parity tests)
         outputs = _forward_with_dp(vit, samples, dp_scales)
     else:
         outputs = model(samples, output_qkv=True)                                   # engine.py:70
     logits, qkvs = outputs['output'], outputs['qkv']
-    teacher_outputs = pre_teacher() if pre_teacher is not None else _teacher_forward(teacher_model, samples)  # engine.py:73-76
+    if teacher_outputs is None:                                                     # engine.py:73-76
+        teacher_outputs = pre_teacher() if pre_teacher is not None else _teacher_forward(teacher_model, samples)
     teacher_logits, teacher_qkvs = teacher_outputs['output'], teacher_outputs['qkv']
     if criterion is None:
         criterion = losses.DistillLoss(losses.SoftTargetCrossEntropy(), kind, alpha, tau)
@@ -85,6 +87,74 @@ def _teacher_forward_async(teacher_model, samples):
     return join
 
 
+class TeacherLookahead:
+    """Frozen-teacher forward one batch ahead (engine.py:73-76 computes it inside the step).
+
+    The teacher has no dependence on the student, so its forward for batch k+1 can be enqueued on the side stream as
+    soon as batch k+1 exists: it then runs beside the student's backward of batch k, and the workgroups of one model
+    fill the partial last rounds of the other's kernels for the whole step, not only during the student forward.
+    Same arithmetic per step; one batch of teacher outputs (logits + one block's q/k/v) stays resident.
+
+        look = TeacherLookahead(teacher); look.submit(batch0)
+        for k: t_out = look.take(batch_k); look.submit(batch_k+1); distill_forward(..., batch_k, teacher_outputs=t_out)
+    """
+
+    def __init__(self, teacher_model):
+        self.teacher = teacher_model
+        if getattr(teacher_model, "qkv_pad_layers", None) is None and hasattr(teacher_model, "blocks"):
+            teacher_model.qkv_pad_layers = {len(teacher_model.blocks) // 2 - 1}
+        self._pending = None
+
+    def submit(self, samples):
+        if self._pending is not None:
+            raise RuntimeError("TeacherLookahead.submit: the previous batch was not taken")
+        self._pending = (samples, _teacher_forward_async(self.teacher, samples))
+
+    def take(self, samples):
+        if self._pending is None or self._pending[0] is not samples:
+            raise RuntimeError("TeacherLookahead.take: not the batch that was submitted")
+        join, self._pending = self._pending[1], None
+        return join()
+
+
+class _PreparedBatches:
+    """data_loader -> (samples on device after mixup, targets, teacher outputs or None), one batch ahead when a
+    TeacherLookahead is given (engine.py:62-68 does the transfer + mixup at the top of each iteration)."""
+
+    def __init__(self, loader, device, mixup_fn, look):
+        self.loader, self.device, self.mixup_fn, self.look = loader, device, mixup_fn, look
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _prep(self, batch):
+        samples, targets = batch
+        samples = samples.to(self.device, non_blocking=True)
+        targets = targets.to(self.device, non_blocking=True)
+        if self.mixup_fn is not None:
+            samples, targets = self.mixup_fn(samples, targets)
+        return samples, targets
+
+    def __iter__(self):
+        it = iter(self.loader)
+        cur = next(it, None)
+        if cur is None:
+            return
+        cur = self._prep(cur)
+        if self.look is not None:
+            self.look.submit(cur[0])
+        while cur is not None:
+            nxt = next(it, None)
+            nxt = self._prep(nxt) if nxt is not None else None
+            t_out = None
+            if self.look is not None:
+                t_out = self.look.take(cur[0])
+                if nxt is not None:
+                    self.look.submit(nxt[0])
+            yield cur[0], cur[1], t_out
+            cur = nxt
+
+
 def _forward_with_dp(vit, samples, dp_scales):
     x = vit.embed(samples)
     xo, qkvs, _, _ = de_vit.run_blocks(list(vit.blocks), x, vit.training, True, False, False,
@@ -105,12 +175,11 @@ def train_1epoch_qkv(model, teacher_model, criterion, data_loader, optimizer, de
         metric_logger.add_meter(name, SmoothedValue(window_size=1, fmt='{value:.6f}'))
     header = 'Epoch: [{}]'.format(epoch)
     step = 0
-    for samples, targets in metric_logger.log_every(data_loader, print_freq, header):
-        samples = samples.to(device, non_blocking=True)
-        targets = targets.to(device, non_blocking=True)
-        if mixup_fn is not None:
-            samples, targets = mixup_fn(samples, targets)
-        out = distill_forward(model, teacher_model, samples, targets, gama=args.gama, criterion=criterion)
+    lookahead = bool(getattr(args, "teacher_lookahead", True)) and device is not None and str(device).startswith("cuda")
+    batches = _PreparedBatches(data_loader, device, mixup_fn, TeacherLookahead(teacher_model) if lookahead else None)
+    for samples, targets, teacher_out in metric_logger.log_every(batches, print_freq, header):
+        out = distill_forward(model, teacher_model, samples, targets, gama=args.gama, criterion=criterion,
+                              teacher_outputs=teacher_out)
         loss = out['loss']
         log_now = (step % print_freq == 0)
         if log_now:

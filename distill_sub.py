@@ -67,6 +67,8 @@ def get_args_parser():
     a('--load_shrink', action='store_true', default=False); a('--shrink_checkpoint', type=str, default='')
     a('--neuron_shrinking', action='store_true', default=False); a('--head_shrinking', action='store_true', default=False)
     a('--synthetic', type=int, default=0, metavar='STEPS', help='train on STEPS random on-device batches per epoch')
+    a('--no-teacher-lookahead', dest='teacher_lookahead', action='store_false',
+      help='run the frozen teacher inside the step instead of one batch ahead (engine.TeacherLookahead)')
     return p
 
 

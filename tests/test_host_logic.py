@@ -83,3 +83,36 @@ def test_flat_params_and_buckets():
     for p in flat.params:                                                          # backward order
         red.mark_ready([p])
     assert fired == list(range(len(red.buckets)))                                  # buckets fire in order
+
+
+def test_prepared_batches_lookahead_order():
+    """engine._PreparedBatches: every batch is yielded once, in order, after transfer + mixup, together with the
+    teacher output that was submitted for exactly that batch one iteration earlier."""
+    import torch
+    from devit_amd import engine
+
+    class FakeLook:
+        def __init__(self):
+            self.pending, self.log = None, []
+
+        def submit(self, samples):
+            assert self.pending is None
+            self.pending = samples
+            self.log.append(("submit", float(samples[0])))
+
+        def take(self, samples):
+            assert self.pending is samples
+            self.pending = None
+            self.log.append(("take", float(samples[0])))
+            return {"output": samples * 10}
+
+    loader = [(torch.tensor([float(i)]), torch.tensor([i])) for i in range(4)]
+    mix = lambda s, t: (s + 0.5, t)
+    look = FakeLook()
+    got = list(engine._PreparedBatches(loader, "cpu", mix, look))
+    assert [float(s[0]) for s, _, _ in got] == [0.5, 1.5, 2.5, 3.5]
+    assert [float(o["output"][0]) for _, _, o in got] == [5.0, 15.0, 25.0, 35.0]
+    assert look.log[:4] == [("submit", 0.5), ("take", 0.5), ("submit", 1.5), ("take", 1.5)] and look.pending is None
+    assert len(engine._PreparedBatches(loader, "cpu", None, None)) == 4
+    assert [o for _, _, o in engine._PreparedBatches(loader, "cpu", None, None)] == [None] * 4
+    assert list(engine._PreparedBatches([], "cpu", None, look)) == []
