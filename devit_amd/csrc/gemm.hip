@@ -197,6 +197,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 // pos-embed) first, then compute + stores -- so that no load queues behind the stores of an earlier row (vmcnt counts
 // loads and stores in order on gfx950).  No LDS is touched: the operand ring is free while the epilogue runs.
 // FULL = every row of the tile is a real row (m < m_lim): no predicates.
+// Epilogue output store: plain.  Measured (tools/gemm_bench.py + bench.py A/B): write-through (sc1) stores -12 % on the
+// GEMM itself; non-temporal stores +2..7 % on the bf16-output GEMMs and -1..11 % on the fp32 residual ones, and no
+// change of the step time (the consumer kernels pay what the producers gain).
+template <typename T>
+__device__ __forceinline__ void st_out(T* p, T v) {
+  *p = v;
+}
+
 __device__ __forceinline__ bf16x8 pack8(const float (&x)[8]) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -304,16 +312,16 @@ __device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 
         for (int j = 0; j < 4; ++j) {
           const f32x4 v = acc[i][j] + bias[j];
           if (KIND == DEVIT_EPI_STORE_F32) {
-            if (ok) *(f32x4*)((float*)ep.out + o + noff[j]) = v;
+            if (ok) st_out((f32x4*)((float*)ep.out + o + noff[j]), v);
           } else if (KIND == DEVIT_EPI_PATCH_F32) {
-            if (ok) *(f32x4*)((float*)ep.out + o + noff[j]) = v + gin[u][j];
+            if (ok) st_out((f32x4*)((float*)ep.out + o + noff[j]), v + gin[u][j]);
           } else {  // RESIDUAL_F32
             if (ok) {
               if (ep.aux) {
                 const bf16x4 pb = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                *(bf16x4*)((__bf16*)ep.aux + o + noff[j]) = pb;
+                st_out((bf16x4*)((__bf16*)ep.aux + o + noff[j]), pb);
               }
-              *(f32x4*)((float*)ep.out + o + noff[j]) = gin[u][j] + rsc[u] * v;
+              st_out((f32x4*)((float*)ep.out + o + noff[j]), gin[u][j] + rsc[u] * v);
             }
           }
         }
@@ -342,11 +350,11 @@ __device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 
         swap_half_rows(outc[0], outc[1], hi);
         if (KIND == DEVIT_EPI_GELU_BF16 && ep.aux) {
           swap_half_rows(prec[0], prec[1], hi);
-          if (okA) *(bf16x8*)((__bf16*)ep.aux + oA) = prec[0];
-          if (okB) *(bf16x8*)((__bf16*)ep.aux + oB) = prec[1];
+          if (okA) st_out((bf16x8*)((__bf16*)ep.aux + oA), prec[0]);
+          if (okB) st_out((bf16x8*)((__bf16*)ep.aux + oB), prec[1]);
         }
-        if (okA) *(bf16x8*)((__bf16*)ep.out + oA) = outc[0];
-        if (okB) *(bf16x8*)((__bf16*)ep.out + oB) = outc[1];
+        if (okA) st_out((bf16x8*)((__bf16*)ep.out + oA), outc[0]);
+        if (okB) st_out((bf16x8*)((__bf16*)ep.out + oB), outc[1]);
       }
     }
   }
@@ -583,13 +591,6 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   g.a_bs = Aop->batch_stride; g.b_bs = Bop->batch_stride;
   g.M = M; g.N = N; g.K = K;
   g.tiles_m = 0; g.tiles_n = 0; g.split_k = split_k;
-  {
-    // keep one chunk of B (gn * 128 rows x K) around 1 MiB so it stays in the XCD's 4 MiB L2 while A streams
-    static const int gn_env = getenv("DEVIT_GEMM_GN") ? atoi(getenv("DEVIT_GEMM_GN")) : 0;
-    int gn = gn_env > 0 ? gn_env : (int)((1 << 20) / ((long long)128 * K * 2));
-    if (gn < 1) gn = 1;
-    g.gn = gn;
-  }
   g.ep = *ep;
   // tile choice: 256x256 (8 waves of 128x64, 2-deep ring) when both dims allow, else 256x128 (8 waves of
   // 64x64, 3-deep ring), else 128x128 (4 waves)
@@ -611,7 +612,21 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   const int bm = cfg == 1 ? 128 : 256, bn = cfg == 3 ? 256 : 128;
   g.tiles_m = M / bm;
   g.tiles_n = N / bn;
-  if (g.gn > g.tiles_n) g.gn = g.tiles_n;
+  {
+    // Tile order inside an XCD: n-tile fastest inside chunks of gn n-tiles, so that the W workgroups an XCD runs at
+    // the same time cover about W / gn m-tiles x gn n-tiles and share their operand panels through the XCD's L2 while
+    // they walk K together.  Fill bytes per K-step are ~ (W / gn) BM + gn BN: smallest near gn = sqrt(W BM / BN)
+    // (8 for two 128x128 workgroups on each of the 32 CUs, 6 for one 256x256).  Measured with FETCH_SIZE on the
+    // teacher fc2 GEMM (K = 3072, three 256-wide n-tiles): gn = 1 fetched the activation panel once per n-tile
+    // (1137 MB per launch against 472 MB algorithmic).
+    static const int gn_env = getenv("DEVIT_GEMM_GN") ? atoi(getenv("DEVIT_GEMM_GN")) : 0;
+    const int per_xcd = (cfg == 1 ? 64 : 32);
+    int target = 1;
+    while ((target + 1) * (target + 1) * bn <= per_xcd * bm + (target + 1) * bn) ++target;   // ~ round(sqrt(W BM / BN))
+    const int nchunks = (g.tiles_n + target - 1) / target;
+    g.gn = gn_env > 0 ? gn_env : (g.tiles_n + nchunks - 1) / nchunks;
+    if (g.gn > g.tiles_n) g.gn = g.tiles_n;
+  }
   const long long tiles = (long long)g.tiles_m * g.tiles_n * split_k * batch;
   DEVIT_CHECK(tiles < (1ll << 31), DEVIT_ERR_SHAPE, "devit_gemm_bf16: too many tiles");
   g.total_tiles = (int)tiles;
