@@ -85,6 +85,18 @@ def cpu_baseline(seconds):
             "sample": f"{n} fp32 DEKD steps (student fwd+bwd, DeiT-B teacher fwd, losses) at bs 8, no optimizer"}
 
 
+def pmc_traffic():
+    """Fabric-side bytes per launch of the dominant template (FETCH_SIZE x 2 + WRITE_SIZE), from the committed
+    rocprofv3 counter passes over this same command (tools/gpu_pmc_traffic.sh -> profiles/*_pmc_traffic.json; the
+    counters cannot be read from inside the process).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -182,9 +194,9 @@ def main():
         d[2] += 1
     dom = "A_row/B_row"
     fl, tm, cnt = by_t[dom]
-    roof = {"bound": "mfma", "kernel": "gemm_kernel<*, A_row, B_row, *> (256x256 / 256x128 x64 bf16 MFMA tiles; fwd Linear layers of teacher + student)",
+    roof = {"bound": "mfma", "kernel": "gemm_kernel<*, A_row, B_row, *> (persistent 128x128 / 256x256 x64 bf16 MFMA tiles; fwd Linear layers of teacher + student)",
             "achieved": round(fl / tm / 1e12, 2), "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": round(fl / tm / BF16_DENSE_PEAK, 4), "traffic": None,
+            "frac": round(fl / tm / BF16_DENSE_PEAK, 4), "traffic": pmc_traffic(),
             "launches_per_step": cnt, "avg_launch_us": round(tm / cnt * 1e6, 2),
             "gflop_per_launch_avg": round(fl / cnt / 1e9, 3),
             "step_frac": round(img_per_s / world * GFLOP_PER_IMG_STEP * 1e9 / BF16_DENSE_PEAK, 4),
