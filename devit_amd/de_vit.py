@@ -132,6 +132,16 @@ class Block(nn.Module):
 
     def block_params(self, device):
         bp = ops.BlockParams()
+        bp.compacted = False
+        c = getattr(self, "_compact", None)
+        if c is not None:            # physically shrunk weights (shrink.compact): gates folded in, masked units gone
+            bp.n1w, bp.n1b, bp.n2w, bp.n2b = self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias
+            bp.qkv_w = bp.proj_w = bp.fc1_w = bp.fc2_w = None
+            bp.qkv_b, bp.proj_b, bp.fc1_b, bp.fc2_b = c["qkv_b"], self.attn.proj.bias, c["fc1_b"], self.mlp.fc2.bias
+            bp.qkv_w16, bp.proj_w16, bp.fc1_w16, bp.fc2_w16 = c["qkv_w16"], c["proj_w16"], c["fc1_w16"], c["fc2_w16"]
+            bp.num_heads, bp.head_gate, bp.neuron_gate = c["num_heads"], None, None
+            bp.dp_prob, bp.module, bp.compacted = 0., self, True
+            return bp
         bp.n1w, bp.n1b = self.norm1.weight, self.norm1.bias
         bp.qkv_w, bp.qkv_b = self.attn.qkv.weight, self.attn.qkv.bias
         bp.proj_w, bp.proj_b = self.attn.proj.weight, self.attn.proj.bias
@@ -202,6 +212,8 @@ def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=Non
     flat = [p for bp in bps for p in bp.all_params()]
     if precision == "f32":
         from . import ops_f32
+        if any(bp.compacted for bp in bps):
+            raise L.DevitError('precision="f32" runs the uncompacted weights: call shrink.uncompact(model) first')
         outs = ops_f32.EncoderF32Fn.apply(x, cfg, *flat)
     else:
         outs = ops.EncoderFn.apply(x, cfg, *flat)

@@ -168,7 +168,7 @@ class BlockParams:
     """fp32 parameters + cached bf16 GEMM copies of one Block (see de_vit.Block)."""
     __slots__ = ("n1w", "n1b", "qkv_w", "qkv_b", "proj_w", "proj_b", "n2w", "n2b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
                  "qkv_w16", "proj_w16", "fc1_w16", "fc2_w16", "num_heads", "head_gate", "neuron_gate", "dp_prob",
-                 "module")
+                 "module", "compacted")
 
     def all_params(self):
         return [self.n1w, self.n1b, self.qkv_w, self.qkv_b, self.proj_w, self.proj_b, self.n2w, self.n2b, self.fc1_w,
@@ -197,12 +197,13 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
     mean1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     rstd1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     layernorm_fwd(x2, M, D, bp.n1w, bp.n1b, cfg.eps, y_bf16=ln1, mean=mean1, rstd=rstd1)
+    Da = bp.qkv_w16.shape[0] // 3          # attention width = heads * 64 (== D unless the block was compacted, shrink.py)
     # the attention kernels never read rows >= B*N; the relation-loss windows (RelationLossFn) overhang by up to 128
-    qkv = rows_alloc(M, 3 * D, BF16, dev, extra=128 if pad_qkv else 0)
+    qkv = rows_alloc(M, 3 * Da, BF16, dev, extra=128 if pad_qkv else 0)
     linear_fwd(ln1, bp.qkv_w16, bp.qkv_b, M, out=qkv)
-    attn_o = rows_alloc(M, D, BF16, dev)
+    attn_o = rows_alloc(M, Da, BF16, dev)
     lse = torch.empty((B, H, N), dtype=F32, device=dev) if need_grad else None
-    call("devit_attn_fwd", ptr(qkv), ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, N, H, D // H, (D // H) ** -0.5,
+    call("devit_attn_fwd", ptr(qkv), ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, N, H, Da // H, (Da // H) ** -0.5,
          stream_ptr())
     x1 = torch.empty((B, N, D), dtype=F32, device=dev)
     att = torch.empty((M, D), dtype=BF16, device=dev) if want_att else None
@@ -213,7 +214,7 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
     mean2 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     rstd2 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     layernorm_fwd(x1.view(M, D), M, D, bp.n2w, bp.n2b, cfg.eps, y_bf16=ln2, mean=mean2, rstd=rstd2)
-    Hd = bp.fc1_w.shape[0]
+    Hd = bp.fc1_w16.shape[0]
     h = rows_alloc(M, Hd, BF16, dev)
     h_pre = rows_alloc(M, Hd, BF16, dev) if need_grad else None
     linear_fwd(ln2, bp.fc1_w16, bp.fc1_b, M, out=h, kind=L.EPI_GELU_BF16, colscale=bp.neuron_gate, aux=h_pre,
@@ -223,7 +224,7 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
                rows_per_scale=N)
     if bp.module is not None:  # shrink contract (core/imp_rank.py:31,108): post-mask values
         bp.module.mlp.neuron_output = h[:M].view(B, N, Hd)
-        bp.module.attn.head_output = attn_o[:M].view(B, N, H, D // H)
+        bp.module.attn.head_output = attn_o[:M].view(B, N, H, Da // H)
     if need_grad:
         s = dict(x=x, ln1=ln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn_o=attn_o, lse=lse, x1=x1, ln2=ln2, mean2=mean2,
                  rstd2=rstd2, h=h, h_pre=h_pre, dp1=dp1, dp2=dp2)
@@ -290,7 +291,10 @@ class EncoderFn(torch.autograd.Function):
     def forward(ctx, x, cfg, *params):
         L.require_device(x)
         x = x.contiguous()
-        need_grad = cfg.grad_enabled and (x.requires_grad or any(p.requires_grad for p in params))
+        need_grad = cfg.grad_enabled and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+        if need_grad and any(getattr(bp, "compacted", False) for bp in cfg.blocks):
+            raise L.DevitError("a compacted model (devit_amd.shrink.compact) is inference-only: run it under "
+                               "torch.no_grad() or call shrink.uncompact(model) before training")
         saved, qkvs, atts, encs = [], [], [], []
         for i, bp in enumerate(cfg.blocks):
             dp = cfg.dp_scales[i] if cfg.dp_scales is not None else None

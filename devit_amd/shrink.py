@@ -1,0 +1,153 @@
+"""Physical shrinking: turn the 0/1 (or real-valued) gates of a trained sub-model into smaller GEMMs.
+
+The reference prunes by MASKING only: `core/imp_rank.py:50-71,132-153` writes `m.gate` for every `Mlp` / `Attention`
+and `models/de_vit.py:42-43,77-79` multiplies the hidden activations / head outputs by it, so a sub-model shrunk by 30 %
+still runs every FLOP of the dense model; the saving exists only in the analytic model of `core/compute_metric.py:44-59`
+(9.20 -> 6.36 GFLOPs at 0.3/0.3).  `compact()` makes it real for inference:
+
+  * Attention: heads with gate == 0 are dropped from the qkv GEMM (rows of `qkv.weight` / `qkv.bias`), from the attention
+    grid and from the proj GEMM (columns of `proj.weight`); a non-zero gate g_h is folded into head h's proj columns.
+  * Mlp: neurons with gate == 0 are dropped from fc1 (rows) and fc2 (columns); g_j is folded into fc2 column j.
+  * Kernel granularity: the hidden width is padded to a multiple of 128 and the head count to an even number with
+    all-zero units (zero weights and bias: gelu(0) = 0, and a head with q = k = v = 0 outputs 0), so the result is
+    EXACTLY the masked model's function.
+
+The fp32 master parameters, `state_dict()` and the gates are untouched; the compacted bf16 weights live beside them
+(`block._compact`) and are used by `Block.block_params`.  Compacted blocks are inference-only (EncoderFn refuses to
+record a backward through them); `uncompact()` drops them.  `neuron_output` / `head_output` of a compacted block hold
+the kept units only.
+"""
+import torch
+
+from . import ops
+
+__all__ = ["compact", "uncompact", "compact_block_weights", "compacted_gflops", "masks_from_sparsity", "load_policy",
+           "get_policy", "save_gates", "load_gates"]
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+@torch.no_grad()
+def compact_block_weights(blk):
+    """fp32 compacted weights of one Block from its current gates (pure tensor indexing: runs on any device).
+    Returns dict(num_heads, qkv_w [3*64*Hr, D], qkv_b, proj_w [D, 64*Hr], fc1_w [Nr, D], fc1_b, fc2_w [D, Nr],
+    kept_heads, kept_neurons)."""
+    attn, mlp = blk.attn, blk.mlp
+    dev = attn.qkv.weight.device
+    D, H = attn.qkv.weight.shape[1], attn.num_heads
+    hd = attn.qkv.weight.shape[0] // (3 * H)
+    hg = attn.gate.detach().float().cpu().reshape(-1)
+    keep_h = torch.nonzero(hg != 0).reshape(-1)
+    Hr = max(2, _round_up(len(keep_h), 2))                       # heads run (3 * 64 * Hr must be a multiple of 128)
+    qw = attn.qkv.weight.detach().float().view(3, H, hd, D)
+    qb = attn.qkv.bias.detach().float().view(3, H, hd)
+    pw = attn.proj.weight.detach().float().view(D, H, hd)
+    kh = keep_h.to(dev)
+    qkv_w = torch.zeros((3, Hr, hd, D), device=dev)
+    qkv_b = torch.zeros((3, Hr, hd), device=dev)
+    proj_w = torch.zeros((D, Hr, hd), device=dev)
+    qkv_w[:, : len(keep_h)] = qw[:, kh]
+    qkv_b[:, : len(keep_h)] = qb[:, kh]
+    proj_w[:, : len(keep_h)] = pw[:, kh] * hg[keep_h].to(dev)[None, :, None]
+    ng = mlp.gate.detach().float().cpu().reshape(-1)
+    keep_n = torch.nonzero(ng != 0).reshape(-1)
+    Nr = max(128, _round_up(len(keep_n), 128))
+    kn = keep_n.to(dev)
+    fc1_w = torch.zeros((Nr, D), device=dev)
+    fc1_b = torch.zeros((Nr,), device=dev)
+    fc2_w = torch.zeros((mlp.fc2.weight.shape[0], Nr), device=dev)
+    fc1_w[: len(keep_n)] = mlp.fc1.weight.detach().float()[kn]
+    fc1_b[: len(keep_n)] = mlp.fc1.bias.detach().float()[kn]
+    fc2_w[:, : len(keep_n)] = mlp.fc2.weight.detach().float()[:, kn] * ng[keep_n].to(dev)[None, :]
+    return dict(num_heads=Hr, qkv_w=qkv_w.reshape(3 * Hr * hd, D).contiguous(), qkv_b=qkv_b.reshape(-1).contiguous(),
+                proj_w=proj_w.reshape(D, Hr * hd).contiguous(), fc1_w=fc1_w, fc1_b=fc1_b, fc2_w=fc2_w,
+                kept_heads=keep_h.tolist(), kept_neurons=keep_n)
+
+
+@torch.no_grad()
+def compact(model):
+    """Build the compacted weights of every block of `model` (a devit_amd VisionTransformer, MultiViT sub-models
+    included) from its current gates.  Returns [(kept heads, heads run, kept neurons, neurons run)] per block."""
+    report = []
+    for blk in _blocks(model):
+        w = compact_block_weights(blk)
+        blk._compact = dict(num_heads=w["num_heads"], qkv_b=w["qkv_b"], fc1_b=w["fc1_b"],
+                            qkv_w16=ops.cast_bf16(w["qkv_w"], None), proj_w16=ops.cast_bf16(w["proj_w"], None),
+                            fc1_w16=ops.cast_bf16(w["fc1_w"], None), fc2_w16=ops.cast_bf16(w["fc2_w"], None),
+                            kept_heads=w["kept_heads"], kept_neurons=w["kept_neurons"])
+        report.append((len(w["kept_heads"]), w["num_heads"], len(w["kept_neurons"]), w["fc1_w"].shape[0]))
+    return report
+
+
+def uncompact(model):
+    for blk in _blocks(model):
+        blk._compact = None
+
+
+def _blocks(model):
+    from .de_vit import Block
+    return [m for m in model.modules() if isinstance(m, Block)]
+
+
+def compacted_gflops(model, tokens=198, patch_dim=768, num_classes=None):
+    """Forward GFLOPs per image (2 FLOP per MAC, the accounting of BASELINE.md §2) of the model as it would run:
+    compacted blocks at their run sizes, the others dense."""
+    total = 0.0
+    for blk in _blocks(model):
+        D = blk.attn.qkv.weight.shape[1]
+        c = getattr(blk, "_compact", None)
+        Da = c["qkv_w16"].shape[0] // 3 if c else D
+        Hd = c["fc1_w16"].shape[0] if c else blk.mlp.fc1.weight.shape[0]
+        total += 2.0 * tokens * (D * 3 * Da + Da * D + 2 * D * Hd) + 4.0 * tokens * tokens * Da
+    for m in model.modules():
+        if type(m).__name__ == "VisionTransformer":
+            D = m.embed_dim
+            total += 2.0 * (tokens - (2 if getattr(m, "dist_token", None) is not None else 1)) * patch_dim * D
+            nc = num_classes if num_classes is not None else getattr(m, "num_classes", 0)
+            total += 2.0 * D * nc * (2 if getattr(m, "head_dist", None) is not None else 1)
+    return total / 1e9
+
+
+def masks_from_sparsity(model, neuron_sparsity, head_sparsity, neuron_rank, head_rank):
+    """core/imp_rank.py:50-62 (`mlp_neuron_mask`) and :132-144 (`attn_head_mask`): per block keep the
+    int(n * (1 - ratio)) highest-ranked units; `*_rank[i]` is an ascending argsort of importance scores."""
+    policy = []
+    for i, blk in enumerate(_blocks(model)):
+        nh, nn_ = blk.attn.num_heads, blk.mlp.hidden_features
+        hm, nm = torch.zeros(nh), torch.zeros(nn_)
+        keep_h = int(nh * (1 - head_sparsity[i]))
+        keep_n = int(nn_ * (1 - neuron_sparsity[i]))
+        hm[list(head_rank[i])[::-1][:keep_h]] = 1
+        nm[list(neuron_rank[i])[::-1][:keep_n]] = 1
+        policy.append((hm, nm))
+    return policy
+
+
+def load_policy(model, policy):
+    """Assign gates from a shrink policy: a sequence over blocks of (head_mask [H], neuron_mask [hidden]) arrays -- the
+    content of the reference's `shrinked_policy.npy` (core/imp_rank.py writes one 0/1 vector per Attention / Mlp in
+    module order)."""
+    blocks = _blocks(model)
+    if len(policy) != len(blocks):
+        raise ValueError(f"policy has {len(policy)} entries for {len(blocks)} blocks")
+    for blk, (hm, nm) in zip(blocks, policy):
+        blk.attn.gate = torch.as_tensor(hm, dtype=torch.float32).reshape(-1).clone()
+        blk.mlp.gate = torch.as_tensor(nm, dtype=torch.float32).reshape(-1).clone()
+
+
+def get_policy(model):
+    """[(head gate [H], neuron gate [hidden])] per block, CPU float tensors."""
+    return [(b.attn.gate.detach().float().cpu().clone(), b.mlp.gate.detach().float().cpu().clone()) for b in _blocks(model)]
+
+
+def save_gates(model, path):
+    """Persist the gates beside a checkpoint.  The reference keeps `gate` out of `state_dict()` (plain attributes,
+    models/de_vit.py:33,63), so a shrunk sub-model reloaded from `checkpoint.pth` runs dense again;
+    the state_dict ABI stays as it is and the gates travel in their own file."""
+    torch.save([(h.numpy(), n.numpy()) for h, n in get_policy(model)], path)
+
+
+def load_gates(model, path):
+    load_policy(model, [(torch.from_numpy(h), torch.from_numpy(n)) for h, n in torch.load(path, weights_only=False)])

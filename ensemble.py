@@ -32,6 +32,10 @@ def get_args_parser():
     p.add_argument('--loss', default='mse', choices=['mse', 'kldiv'], type=str, help="loss type")
     p.add_argument('--dataset', default='cifar100', choices=['cifar100', 'IMNET', 'INAT', 'INAT19'])
     p.add_argument('--sub_classes', nargs='+', default=[25, 25, 25, 25])
+    p.add_argument('--gates', default='', help='file written by devit_amd.shrink.save_gates for the MultiViT '
+                                               '(the reference drops the gates of shrunk sub-models on reload)')
+    p.add_argument('--physical-shrink', action='store_true',
+                   help='--eval only: remove the gated-off heads / neurons from the GEMMs (devit_amd.shrink.compact)')
     return p
 
 
@@ -75,7 +79,15 @@ def main(args):
     mixup_fn = ds.Mixup(args.mixup, args.cutmix, args.mixup_prob, args.mixup_switch_prob, args.smoothing, num_classes) \
         if (args.mixup > 0 or args.cutmix > 0.) else None
     teacher, model, ens_model = get_models(args, len(sub_classes), sub_classes, num_classes)
+    if args.gates:
+        from devit_amd import shrink
+        shrink.load_gates(model, args.gates)
     if args.eval:
+        if args.physical_shrink:
+            from devit_amd import shrink
+            rep = shrink.compact(model)
+            print(f"physically shrunk {len(rep)} blocks: heads run {sorted(set(r[1] for r in rep))}, "
+                  f"hidden widths run {sorted(set(r[3] for r in rep))}")
         print(engine.evaluate_ens_disjoint(val_loader, model, ens_model, device))
         return
     lr = args.lr * args.batch_size * utils.get_world_size() / 512.0

@@ -274,3 +274,49 @@ def test_ensemble_vs_golden(golden, dev):
     with torch.no_grad():
         le = ens(multi(img))
     assert rel(le, g["logits_eval"]) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ physical shrinking (§8f-2)
+def test_compacted_model_equals_masked_model(models, dev):
+    """shrink.compact(): the physically shrunk student (masked heads / neurons removed from the GEMMs and the attention
+    grid) computes the masked model's function -- against the masked HIP model and against the CPU oracle with gates."""
+    from devit_amd import _lib, shrink
+    s, _, st_s, _ = models
+    g = torch.Generator().manual_seed(7)
+    head_gates, neuron_gates = [], []
+    for i, blk in enumerate(s.blocks):
+        hm = torch.ones(6)
+        hm[torch.randperm(6, generator=g)[: (1 if i % 3 == 0 else 2)]] = 0          # 5 kept (-> 6 run) or 4 kept
+        nm = torch.ones(1536)
+        nm[torch.randperm(1536, generator=g)[:461]] = 0                              # shrink_ratio 0.3
+        blk.attn.gate, blk.mlp.gate = hm, nm
+        head_gates.append(hm)
+        neuron_gates.append(nm)
+    img = torch.from_numpy(det_array("shrink", (4, 3, 224, 224), std=0.7))
+    try:
+        s.eval()
+        with torch.no_grad():
+            ref = O.forward(st_s, GS, img, training=False, head_gates=head_gates, neuron_gates=neuron_gates)["output"]
+            masked = s(img.to(dev), output_qkv=True)
+            rep = shrink.compact(s)
+            assert all(hr in (4, 6) and nr == 1152 for _, hr, _, nr in rep)
+            dense_gf, compact_gf = 9.247, shrink.compacted_gflops(s, num_classes=C)
+            assert 0.70 * dense_gf < compact_gf < 0.80 * dense_gf
+            comp = s(img.to(dev), output_qkv=True)
+        assert rel(comp["output"], masked["output"].float().cpu().numpy()) < 5e-3      # same bf16 path, fewer zero terms
+        assert rel(comp["output"], ref.numpy()) < 3e-2 and torch.equal(comp["output"].argmax(1).cpu(), ref.argmax(1))
+        assert comp["qkv"][0][0].shape[1] == rep[0][1]                                 # q of block 0: [B, heads run, N, 64]
+        assert s.blocks[0].mlp.neuron_output.shape[-1] == 1152
+        s.train()
+        with pytest.raises(_lib.DevitError):                                           # inference-only
+            s(img.to(dev))
+        shrink.uncompact(s)
+        s.eval()
+        with torch.no_grad():
+            again = s(img.to(dev))
+        assert torch.equal(again, masked["output"])
+    finally:
+        shrink.uncompact(s)
+        for blk in s.blocks:
+            blk.attn.gate, blk.mlp.gate = torch.ones(6), torch.ones(1536)
+        s.train()

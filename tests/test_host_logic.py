@@ -116,3 +116,66 @@ def test_prepared_batches_lookahead_order():
     assert len(engine._PreparedBatches(loader, "cpu", None, None)) == 4
     assert [o for _, _, o in engine._PreparedBatches(loader, "cpu", None, None)] == [None] * 4
     assert list(engine._PreparedBatches([], "cpu", None, look)) == []
+
+
+def test_compact_block_weights_equal_masked_block():
+    """shrink.compact_block_weights: the compacted weights compute exactly the masked block (models/de_vit.py:35-47,
+    65-87 with gates), zero-padded units included; non-binary gates are folded into proj / fc2."""
+    import torch
+    import torch.nn.functional as F
+    from devit_amd import de_vit, shrink
+    from oracle import devit_oracle as O
+
+    torch.manual_seed(0)
+    D, H = 384, 6
+    blk = de_vit.Block(D, H, mlp_ratio=4., qkv_bias=True)
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    hg = torch.tensor([1., 0., 0.5, 1., 0., 1.])                  # 4 kept -> 4 run; one real-valued gate
+    ng = (torch.rand(1536) > 0.3).float()
+    ng[5] = 0.25
+    blk.attn.gate, blk.mlp.gate = hg, ng
+    w = shrink.compact_block_weights(blk)
+    assert w["num_heads"] == 4 and w["qkv_w"].shape == (3 * 256, D) and w["proj_w"].shape == (D, 256)
+    assert w["fc1_w"].shape[0] % 128 == 0 and w["fc1_w"].shape[0] >= int((ng != 0).sum()) > w["fc1_w"].shape[0] - 128
+    st = {"a.qkv.weight": blk.attn.qkv.weight, "a.qkv.bias": blk.attn.qkv.bias, "a.proj.weight": blk.attn.proj.weight,
+          "a.proj.bias": blk.attn.proj.bias, "m.fc1.weight": blk.mlp.fc1.weight, "m.fc1.bias": blk.mlp.fc1.bias,
+          "m.fc2.weight": blk.mlp.fc2.weight, "m.fc2.bias": blk.mlp.fc2.bias}
+    x = torch.randn(2, 50, D)
+    with torch.no_grad():
+        ref_a, _, _ = O.attention(st, "a.", x, H, head_gate=hg)
+        ref_m, _ = O.mlp(st, "m.", x, neuron_gate=ng)
+        Hr = w["num_heads"]
+        qkv = F.linear(x, w["qkv_w"], w["qkv_b"]).reshape(2, 50, 3, Hr, 64).permute(2, 0, 3, 1, 4)
+        a = ((qkv[0] @ qkv[1].transpose(-2, -1)) * 0.125).softmax(-1)
+        got_a = F.linear((a @ qkv[2]).transpose(1, 2).reshape(2, 50, Hr * 64), w["proj_w"], blk.attn.proj.bias)
+        got_m = F.linear(F.gelu(F.linear(x, w["fc1_w"], w["fc1_b"])), w["fc2_w"], blk.mlp.fc2.bias)
+    assert float((got_a - ref_a).abs().max()) < 2e-5 * float(ref_a.abs().max())
+    assert float((got_m - ref_m).abs().max()) < 2e-5 * float(ref_m.abs().max())
+    # odd number of kept heads -> one all-zero head is run; nothing kept -> minimum sizes
+    blk.attn.gate = torch.tensor([1., 1., 1., 0., 0., 0.])
+    assert shrink.compact_block_weights(blk)["num_heads"] == 4
+    blk.attn.gate, blk.mlp.gate = torch.zeros(6), torch.zeros(1536)
+    w0 = shrink.compact_block_weights(blk)
+    assert w0["num_heads"] == 2 and w0["fc1_w"].shape[0] == 128 and float(w0["qkv_w"].abs().max()) == 0.0
+    # masks from sparsities (core/imp_rank.py:50-62,132-144)
+    class M(torch.nn.Module):
+        def __init__(s):
+            super().__init__(); s.b = blk
+    pol = shrink.masks_from_sparsity(M(), [0.3], [0.34], [list(range(1536))], [[3, 1, 0, 2, 5, 4]])
+    assert int(pol[0][0].sum()) == int(6 * (1 - 0.34)) == 3 and pol[0][0].tolist() == [0., 0., 1., 0., 1., 1.]
+    assert int(pol[0][1].sum()) == int(1536 * 0.7) and pol[0][1][-1] == 1 and pol[0][1][0] == 0
+
+
+def test_gate_persistence_roundtrip(tmp_path):
+    import torch
+    from devit_amd import de_vit, shrink
+    blk = de_vit.Block(384, 6, qkv_bias=True)
+    holder = torch.nn.Sequential(blk)
+    hm, nm = torch.tensor([1., 0., 1., 1., 0., 1.]), (torch.arange(1536) % 3 != 0).float()
+    shrink.load_policy(holder, [(hm, nm)])
+    shrink.save_gates(holder, tmp_path / "gates.pt")
+    shrink.load_policy(holder, [(torch.ones(6), torch.ones(1536))])
+    shrink.load_gates(holder, tmp_path / "gates.pt")
+    assert torch.equal(blk.attn.gate, hm) and torch.equal(blk.mlp.gate, nm)
+    assert "gate" not in "".join(holder.state_dict().keys())          # checkpoint ABI unchanged
