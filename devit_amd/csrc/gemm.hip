@@ -435,8 +435,15 @@ void gemm_kernel(const GemmArgs g) {
   bool p_open = true;                                   // false: nothing (more) to request right now
   auto produce = [&]() {
     char* buf = smem + p_slot * STAGE_BYTES;
+#ifdef DEVIT_GEMM_NODMA       // diagnostic build: MFMAs + LDS reads alone (operands are whatever the LDS holds)
+    if (g.K >= 0) buf = nullptr;
+    if (buf != nullptr) {
+#endif
     stage_tile<A_KM, BM, NWAVES>(pt.a, g.lda, (pt.kt0 + p_t) * BK, g.a_group, g.a_skip, buf, wave, lane);
     stage_tile<B_KM, BN, NWAVES>(pt.b, g.ldb, (pt.kt0 + p_t) * BK, g.b_group, g.b_skip, buf + A_TILE_BYTES, wave, lane);
+#ifdef DEVIT_GEMM_NODMA
+    }
+#endif
     p_slot = p_slot + 1 == NSTAGE ? 0 : p_slot + 1;
     ++inflight;
     if (++p_t == pt.nk) {
@@ -473,6 +480,9 @@ void gemm_kernel(const GemmArgs g) {
     auto kstep = [&]() {
       const char* cur = smem + c_slot * STAGE_BYTES;
       c_slot = c_slot + 1 == NSTAGE ? 0 : c_slot + 1;
+#ifdef DEVIT_GEMM_NOCOMPUTE   // diagnostic build: the fill pipeline alone
+      if (g.K < 0)
+#endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 af[MI], bfr[NI];

@@ -52,6 +52,53 @@ def test_gemm_nt_store(dev, M, N, K):
     assert relerr(out32, ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,kind,mv", [
+    (16384, 1152, 384, 0, 0),        # 128x128 tiles: 1152 tiles on <= 512 persistent workgroups (2-3 tiles each, 5+4 n-chunks)
+    (12800, 2304, 768, 0, 0),        # 256x256 tiles: 450 tiles on 256 workgroups, uneven shares, K = 12 ring stages per tile
+    (4096, 768, 1536, 2, 3900),      # 256x256 residual epilogue with padding rows in the last m-tile
+    (9088, 384, 1536, 6, 9000),      # 71 x 3 = 213 tiles (not a multiple of 8), fp32 store, ragged M
+    (6400, 1536, 384, 1, 0),         # GELU + pre-activation, many tiles per workgroup
+])
+def test_gemm_persistent_schedule(dev, M, N, K, kind, mv):
+    """Every output tile of a launch whose workgroups each walk SEVERAL tiles through one continuous LDS ring (cross-tile
+    prefetch, tile decode, n-chunked XCD order) against fp32 matmul; rows >= m_valid stay untouched."""
+    from devit_amd import ops, _lib as L
+    a, w, bias = rnd((M, K), dev, dtype=BF16), rnd((N, K), dev, 0.05, 1, BF16), rnd((N,), dev, 0.1, 2)
+    ref = a.float() @ w.float().t() + bias
+    lim = mv or M
+    if kind == L.EPI_STORE_BF16:
+        out = torch.full((M, N), 3.0, dtype=BF16, device=dev)
+        ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, bias=bias, m_valid=mv)
+        bf16_ulp_ok(out[:lim], ref[:lim])
+    elif kind == L.EPI_GELU_BF16:
+        out = torch.empty((M, N), dtype=BF16, device=dev)
+        pre = torch.empty((M, N), dtype=BF16, device=dev)
+        ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, bias=bias, aux=pre)
+        bf16_ulp_ok(pre, ref)
+        bf16_ulp_ok(out, torch.nn.functional.gelu(ref), extra=1e-4)
+    elif kind == L.EPI_RESIDUAL_F32:
+        res = rnd((M, N), dev, seed=8)
+        out = torch.full((M, N), 3.0, dtype=F32, device=dev)
+        ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, bias=bias, res=res, m_valid=mv)
+        assert relerr(out[:lim], (res + ref)[:lim]) < 2e-5
+    else:
+        out = torch.full((M, N), 3.0, dtype=F32, device=dev)
+        ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, bias=bias, m_valid=mv)
+        assert relerr(out[:lim], ref[:lim]) < 2e-5
+    assert bool((out[lim:].float() == 3.0).all())
+
+
+def test_gemm_wgrad_persistent(dev):
+    """Split-K atomic epilogue with more (tile, slice) work items than persistent workgroups: the ring restarts on every
+    tile (the epilogue stages through its LDS)."""
+    from devit_amd import ops, _lib as L
+    rows, N, K, split = 16384, 1536, 384, 20                       # 12 x 3 tiles x 20 slices = 720 work items
+    dy, x = rnd((rows, N), dev, dtype=BF16), rnd((rows, K), dev, seed=3, dtype=BF16)
+    out = torch.zeros((N, K), dtype=F32, device=dev)
+    ops.gemm(dy, N, 1, x, K, 1, N, K, rows, kind=L.EPI_ATOMIC_F32, out=out, ldc=K, split_k=split)
+    assert relerr(out, dy.float().t() @ x.float()) < 2e-5
+
+
 def test_gemm_layout_asymmetric(dev):
     """A = I-like selector with an asymmetric B catches swapped row/col maps (cdna guide §3)."""
     from devit_amd import ops, _lib as L

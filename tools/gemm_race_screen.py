@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Race screen for the persistent GEMM ring: every (shape, epilogue) is run REPS times on fresh random operands and
+compared bit-for-bit with a second run of the same launch and with an fp32 reference; the kernel is deterministic, so
+any difference between two runs is an LDS-DMA / ds_read ordering bug that a single passing check can miss."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from devit_amd import ops, _lib as L
+dev = torch.device("cuda"); BF = torch.bfloat16
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+cases = [(50688, 1152, 384, 0, 0), (50688, 2304, 768, 0, 0), (50688, 768, 3072, 2, 0), (50688, 1536, 384, 1, 0),
+         (50688, 384, 1536, 0, 1), (50688, 1536, 384, 4, 1), (12800, 2304, 768, 0, 0), (9088, 384, 1536, 6, 0)]
+bad = 0
+for M, N, K, kind, bkm in cases:
+    worst = 0.0
+    for rep in range(REPS):
+        g = torch.Generator(device=dev).manual_seed(rep * 7919 + M + N)
+        a = torch.randn(M, K, generator=g, device=dev).to(BF)
+        w = (torch.randn((K, N) if bkm else (N, K), generator=g, device=dev) * 0.05).to(BF)
+        bias = torch.randn(N, generator=g, device=dev)
+        f32 = kind in (2, 6)
+        kw = {}
+        if kind == 2: kw["res"] = torch.randn(M, N, generator=g, device=dev)
+        if kind == 4: kw["aux_in"] = torch.randn(M, N, generator=g, device=dev).to(BF)
+        outs = []
+        for _ in range(2):
+            out = torch.empty(M, N, dtype=torch.float32 if f32 else BF, device=dev)
+            ops.gemm(a, K, 0, w, N if bkm else K, bkm, M, N, K, kind=kind, out=out, ldc=N, bias=None if kind == 4 else bias, **kw)
+            outs.append(out)
+        if not torch.equal(outs[0], outs[1]):
+            bad += 1
+            print(f"NON-DETERMINISTIC: {M}x{N}x{K} kind {kind} rep {rep}: {int((outs[0] != outs[1]).sum())} elements differ")
+        if kind in (0, 6) :
+            ref = a.float() @ (w.float() if bkm else w.float().t()) + bias
+            worst = max(worst, float((outs[0].float() - ref).abs().max() / ref.abs().max()))
+    print(f"{M}x{N}x{K} kind {kind} b_km {bkm}: {REPS} reps ok, worst rel err vs fp32 {worst:.2e}", flush=True)
+print("race screen:", "FAILED" if bad else "clean")
+sys.exit(1 if bad else 0)
