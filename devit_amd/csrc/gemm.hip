@@ -453,6 +453,78 @@ void gemm_kernel(const GemmArgs g) {
       else p_open = false;
     }
   };
+  // ---------------------------------------------------------------------------------------------------------------
+  // Ping-pong schedule (256x256 tile: the two waves of a SIMD are wm = 0 and wm = 1 of the SAME workgroup).  With one
+  // barrier per K-step all eight waves read their fragments at the same time (96 KB through the LDS while every MFMA
+  // pipe idles) and then all issue MFMAs at the same time: SQ_VALU_MFMA_BUSY_CYCLES showed the pipes 51 % busy with
+  // the DMA removed.  Here a K-step is four barrier intervals -- reads(kk=0) | MFMA(0) | reads(1) | MFMA(1) -- and the
+  // wm = 1 waves run ONE interval behind the wm = 0 waves (one extra barrier before a tile's first K-step, one extra
+  // for wm = 0 after its last): in every interval one wave of each SIMD issues its 32 MFMAs while the other reads its next fragments.
+  //   interval a: request stage t+1 (overwrites the slot read in step t-1), ds_read fragments kk = 0, lgkmcnt(0)
+  //   interval b: MFMA kk = 0
+  //   interval c: ds_read fragments kk = 1, lgkmcnt(0), vmcnt(0) (this wave's share of stage t+1 has landed)
+  //   interval d: MFMA kk = 1
+  // RAW: a wave reads stage t+1 after its barrier Y1(t); the lagging group passed its own vmcnt(0) before its X1(t),
+  // which is the same barrier event.  WAR: stage t+1's slot was last read in interval c of step t-1, retired by the
+  // lgkmcnt(0) in front of X1(t-1), at least one barrier event before any wave requests stage t+1.
+  if constexpr (DIRECT && BM == 256 && BN == 256 && NSTAGE == 2 && WAVES_M == 2) {
+    auto fence = [&]() {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar = [&]() {
+      fence();
+      __builtin_amdgcn_s_barrier();
+      fence();
+    };
+    produce();                         // stage 0 of the first tile
+    wait_vmcnt<0>();
+    bar();
+    int c_slot = 0;
+    for (int tile = first; tile < last; tile += stride) {
+      const TileRef ct = decode_tile<BM, BN, A_KM, B_KM>(g, tile);
+      f32x4 acc[MI][NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const devit_epilogue& ep = g.ep;
+      const int nw = ct.n0 + wn * WN;
+      int noff[4];
+      f32x4 bias[4], cs[4];
+      if (wm == 1) bar();              // the offset: this group now runs one interval behind
+      for (int t = 0; t < ct.nk; ++t) {
+        const char* cur = smem + c_slot * STAGE_BYTES;
+        c_slot ^= 1;
+        if (p_open) produce();
+        if (t == ct.nk - 1) load_cols<KIND>(ep, lane, nw, noff, bias, cs);   // under the last K-step
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 af[MI], bfr[NI];
+#pragma unroll
+          for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN, PAIRED>(cur + A_TILE_BYTES, wn * WN, j, kk, lane);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM, false>(cur, wm * WM, i, kk, lane);
+          if (kk == 1) wait_vmcnt<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          bar();
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
+          bar();
+        }
+      }
+      if (wm == 0) bar();              // pairs with the lagging group's last barrier: both groups run the epilogue
+      settle_cols<KIND>(bias, cs);     // together (one after the other would double its MFMA-idle time)
+      const size_t ob = (size_t)ct.bz * ep.out_batch_stride;
+      const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
+      if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+      else epilogue_direct<KIND, MI, false>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+    }
+    return;
+  }
+
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (p_open) produce();
@@ -606,14 +678,17 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   // 64x64, 3-deep ring), else 128x128 (4 waves)
   const int variant = (a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0);
   static const int force = getenv("DEVIT_GEMM_TILE") ? atoi(getenv("DEVIT_GEMM_TILE")) : 0;  // 1: 128x128, 2: 256x128
-  // Measured on the step's shapes (tools/gemm_tiles.py, M = 50688): 256x256 (one workgroup per CU) wins only when the
-  // K loop is long enough to amortise its un-overlapped prologue/epilogue -- teacher qkv (K 768, plain store) 902 vs
-  // 770 TFLOP/s, fc2 (K 3072) 735 vs 675 -- while 128x128 (two workgroups per CU, one's epilogue under the other's
-  // MFMAs) wins every short-K or epilogue-heavy shape (student qkv 681 vs 624, fc1+GELU 391 vs 369, fc2 558 vs 496,
-  // teacher fc1+GELU 659 vs 629, proj 475 vs 429, fc1 wgrad 640 vs 536).  256x128 won nowhere (kept for experiments).
+  // Measured on the step's shapes (tools/gemm_tiles.py + tools/gpu_tiles.sh, M = 50688, TFLOP/s 256x256 vs 128x128):
+  // the ping-pong 256x256 tile wins the long-K and plain-store shapes (teacher qkv 915-950 vs 838, fc2 K 3072 786 vs
+  // 778) and the VALU-heavy GELU / dGELU epilogues at any K (student fc1 484 vs 452, teacher fc1 842 vs 817, fc2
+  // dgrad 499 vs 481: one wave of each SIMD pair keeps the MFMA pipe while the other is in its epilogue only with two
+  // workgroups per CU, but the fused GELU now costs less than the tile's extra fill traffic); the fp32 residual
+  // epilogue at K <= 768 stays on 128x128 (teacher proj 458 vs 442), as does everything whose N is not a multiple
+  // of 256 and the split-K wgrads.  256x128 won nowhere (kept for experiments).
   const bool light_epi = ep->kind == DEVIT_EPI_STORE_BF16 || ep->kind == DEVIT_EPI_STORE_F32;
+  const bool gelu_epi = ep->kind == DEVIT_EPI_GELU_BF16 || ep->kind == DEVIT_EPI_DGELU_BF16;
   int cfg = 1;
-  if (M % 256 == 0 && N % 256 == 0 && (K >= 1536 || (K >= 768 && light_epi)) && variant != 3) cfg = 3;
+  if (M % 256 == 0 && N % 256 == 0 && (K >= 1536 || (K >= 768 && light_epi) || gelu_epi) && variant != 3) cfg = 3;
   static const int wg_cfg = getenv("DEVIT_GEMM_WGRAD_TILE") ? atoi(getenv("DEVIT_GEMM_WGRAD_TILE")) : 0;
   if (variant == 3 && wg_cfg > 0) cfg = wg_cfg;
   if (force > 0 && force < cfg) cfg = force;
