@@ -40,26 +40,34 @@ __device__ __forceinline__ bf16x8 pbuf_tr_frag(const char* buf, int k0, int c0, 
   return cat8(lds_tr_read(a), lds_tr_read(a + 4 * PSTRIDE * 2));
 }
 
-// Copy rows [0, KROWS) of a strided [N][64] bf16 matrix into an LDS image, zero rows >= N.
-// All 7 loads of a thread are issued before the first LDS write (one HBM latency, not seven).
-template <int NT = 256>
-__device__ __forceinline__ void load_image(char* img, const __bf16* src, size_t row_stride, int N, float mul, int tid) {
-  constexpr int ITERS = (KROWS * 8 + NT - 1) / NT;
+// Rows [0, KROWS) of a strided [N][64] bf16 matrix -> an LDS image (rows >= N zero), in two halves so that a kernel
+// can issue the global loads of ALL its images before the first LDS write: one exposed HBM latency per workgroup
+// instead of one per image.
+template <int NT>
+struct RowRegs {
+  static constexpr int ITERS = (KROWS * 8 + NT - 1) / NT;
   bf16x8 v[ITERS];
+};
+template <int NT>
+__device__ __forceinline__ void fetch_rows(RowRegs<NT>& r, const __bf16* src, size_t row_stride, int N, int tid) {
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
+  for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
     const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    v[it] = row < N ? *(const bf16x8*)(src + (size_t)row * row_stride + c * 8) : z;
+    r.v[it] = row < N ? *(const bf16x8*)(src + (size_t)row * row_stride + c * 8) : z;
   }
+}
+template <int NT>
+__device__ __forceinline__ void put_image(char* img, const RowRegs<NT>& r, float mul, int tid) {
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
+  for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
     const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
+    bf16x8 v = r.v[it];
     if (mul != 1.0f) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[it][e] = f2bf(bf2f(v[it][e]) * mul);
+      for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * mul);
     }
-    if (row < KROWS) *(bf16x8*)(img + img_off(row, c)) = v[it];
+    if (row < KROWS) *(bf16x8*)(img + img_off(row, c)) = v;
   }
 }
 
@@ -105,8 +113,13 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
       qall[it][kk] = (wave + it * FWD_WAVES < ntile && q_ < N) ? *(const bf16x8*)(qbase + (size_t)q_ * rs + kk * 32 + g * 8) : z;
     }
   }
-  load_image<FWD_WAVES * 64>(k_img, qbase + D, rs, N, 1.0f, tid);
-  load_image<FWD_WAVES * 64>(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
+  {
+    RowRegs<FWD_WAVES * 64> kr, vr;
+    fetch_rows(kr, qbase + D, rs, N, tid);
+    fetch_rows(vr, qbase + 2 * D, rs, N, tid);
+    put_image(k_img, kr, 1.0f, tid);
+    put_image(v_img, vr, 1.0f, tid);
+  }
   __syncthreads();
   const int tmask = N >> 4;                          // first key tile that contains a key >= N
 
@@ -231,33 +244,34 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
   const __bf16* dobase = a.dout + (size_t)b * N * D + h * HD;
   const __bf16* obase = a.out + (size_t)b * N * D + h * HD;
 
-  load_image<BWD_WAVES * 64>(q_img, qbase, rs, N, 1.0f, tid);
-  load_image<BWD_WAVES * 64>(k_img, qbase + D, rs, N, 1.0f, tid);
-  load_image<BWD_WAVES * 64>(v_img, qbase + 2 * D, rs, N, 1.0f, tid);
-  load_image<BWD_WAVES * 64>(do_img, dobase, (size_t)D, N, gate, tid);
-  // zero both dS^T buffers once: key rows of tiles that are never written (>= ntile) must read as 0 in dQ
-  for (int i = tid; i < 2 * DST_BYTES / 16; i += BWD_WAVES * 64) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // lse (log2 domain) and delta[q] = sum_d dO[q][d] O[q][d]: 8 lanes per row, one 16-byte chunk each; all loads
-  // are issued before the first use (one exposed latency)
   {
-    constexpr int DIT = (KROWS * 8 + BWD_WAVES * 64 - 1) / (BWD_WAVES * 64);
-    bf16x8 xd[DIT], yd[DIT];
-    float ls[DIT];
+    // every global load of the prologue (four images, O rows and lse for delta) is issued before the first LDS write
+    constexpr int NT = BWD_WAVES * 64;
+    RowRegs<NT> qr, kr, vr, dr, orr;
+    float ls[RowRegs<NT>::ITERS];
+    fetch_rows(qr, qbase, rs, N, tid);
+    fetch_rows(kr, qbase + D, rs, N, tid);
+    fetch_rows(vr, qbase + 2 * D, rs, N, tid);
+    fetch_rows(dr, dobase, (size_t)D, N, tid);
+    fetch_rows(orr, obase, (size_t)D, N, tid);
 #pragma unroll
-    for (int it = 0; it < DIT; ++it) {
-      const int idx = tid + it * BWD_WAVES * 64, row = idx >> 3, c = idx & 7;
-      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      const bool ok = row < N;
-      xd[it] = ok ? *(const bf16x8*)(dobase + (size_t)row * D + c * 8) : z;
-      yd[it] = ok ? *(const bf16x8*)(obase + (size_t)row * D + c * 8) : z;
-      ls[it] = (ok && c == 0) ? a.lse[((size_t)b * a.H + h) * N + row] * 1.4426950408889634f : 0.f;
+    for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
+      const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
+      ls[it] = (row < N && c == 0) ? a.lse[((size_t)b * a.H + h) * N + row] * 1.4426950408889634f : 0.f;
     }
+    // zero both dS^T buffers once: key rows of tiles that are never written (>= ntile) must read as 0 in dQ
+    for (int i = tid; i < 2 * DST_BYTES / 16; i += NT) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    put_image(q_img, qr, 1.0f, tid);
+    put_image(k_img, kr, 1.0f, tid);
+    put_image(v_img, vr, 1.0f, tid);
+    // lse (log2 domain) and delta[q] = sum_d dO[q][d] O[q][d] (unscaled dO: O is the post-gate output): 8 lanes per row,
+    // one 16-byte chunk each, from the registers that also fill the dO image
 #pragma unroll
-    for (int it = 0; it < DIT; ++it) {
-      const int idx = tid + it * BWD_WAVES * 64, row = idx >> 3, c = idx & 7;
+    for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
+      const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
       float dl = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dl += bf2f(xd[it][e]) * bf2f(yd[it][e]);
+      for (int e = 0; e < 8; ++e) dl += bf2f(dr.v[it][e]) * bf2f(orr.v[it][e]);
       dl += __shfl_xor(dl, 1, 64);
       dl += __shfl_xor(dl, 2, 64);
       dl += __shfl_xor(dl, 4, 64);
@@ -266,6 +280,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
         lse2[row] = ls[it];
       }
     }
+    put_image(do_img, dr, gate, tid);
   }
   __syncthreads();
 

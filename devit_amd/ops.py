@@ -602,7 +602,7 @@ class RelationLossFn(torch.autograd.Function):
         s_qkv = ctx.s_qkv
         dev = s_qkv.device
         g = g.contiguous().float()
-        d = torch.zeros_like(s_qkv)
+        d = torch.empty_like(s_qkv)       # rows < B*N are all written below (N rows per image x 3 components)
         S = torch.empty((B, 256, 256), dtype=BF16, device=dev)
         for j in range(3):
             gt, gs = ctx.grams[j]
