@@ -147,6 +147,13 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* A, long l
     const float* b = B + n * sbn;
     float s = 0.f;
     int k = 0;
+    for (; k + 32 <= K; k += 32) {     // 64 independent loads in flight (the kernel is one load latency per trip: K / 8
+      float av[32], bv[32];            // trips took 49 us at K = 384), then the fmaf chain in k order
+#pragma unroll
+      for (int u = 0; u < 32; ++u) { av[u] = a[(k + u) * sak]; bv[u] = b[(k + u) * sbk]; }
+#pragma unroll
+      for (int u = 0; u < 32; ++u) s = fmaf(av[u], bv[u], s);
+    }
     for (; k + 8 <= K; k += 8) {       // 16 independent loads in flight, then the fmaf chain in k order
       float av[8], bv[8];
 #pragma unroll
