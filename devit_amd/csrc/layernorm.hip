@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int LN_MAX_NV = 8;  // D <= 1024, D % 128 == 0 ; lane holds NV float2 pairs
+constexpr int LN_MAX_NV = 8;  // D <= 1024, D % 128 == 0 ; half-wave lane holds NV float4
 
 struct LnFwdArgs {
   const float* x;
@@ -25,52 +25,66 @@ __device__ __forceinline__ size_t ln_in_row(int r, int group, int stride) {
   return group > 0 ? (size_t)(r / group) * stride + (r % group) : (size_t)r;
 }
 
+// Half a wave (32 lanes) per row, 16-byte loads: lane l holds float4 v of the row at columns (v * 32 + l) * 4,
+// NV = D / 128 of them; bf16 output leaves as 8-byte stores.  (The first version read float2 per lane with one wave
+// per row: 2.6-3.1 TB/s from cold HBM, tools/ln_cold.py.)  Statistics: two-pass (mean, then centred sum of squares)
+// in fp32, reduced over the 32 lanes by xor shuffles.
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * 4;
-  f32x2 gm[NV], bt[NV];
+  const int lane = threadIdx.x & 63, l32 = lane & 31, sub = lane >> 5;
+  const int half_global = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + sub;
+  const int nhalves = gridDim.x * 8;
+  f32x4 gm[NV], bt[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    gm[v] = *(const f32x2*)(a.gamma + v * 128 + lane * 2);
-    bt[v] = *(const f32x2*)(a.beta + v * 128 + lane * 2);
+    gm[v] = *(const f32x4*)(a.gamma + (v * 32 + l32) * 4);
+    bt[v] = *(const f32x4*)(a.beta + (v * 32 + l32) * 4);
   }
   const float invD = 1.0f / (float)a.D;
-  for (int r = wave_global; r < a.rows; r += nwaves) {
+  // both halves of a wave run the same number of trips (the shuffles need every lane): a half past the end redoes
+  // the last row and skips its stores
+  const int trips = (a.rows + nhalves - 1) / nhalves;
+  for (int it = 0; it < trips; ++it) {
+    const int rr = half_global + it * nhalves;
+    const bool live = rr < a.rows;
+    const int r = live ? rr : a.rows - 1;
     const float* xr = a.x + ln_in_row(r, a.in_group, a.in_stride) * a.D;
-    f32x2 xv[NV];
+    f32x4 xv[NV];
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      xv[v] = *(const f32x2*)(xr + v * 128 + lane * 2);
-      s += xv[v][0] + xv[v][1];
+      xv[v] = load_stream((const f32x4*)(xr + (v * 32 + l32) * 4));
+      s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
     }
-    const float mu = wave_sum(s) * invD;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s * invD;
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const float d0 = xv[v][0] - mu, d1 = xv[v][1] - mu;
-      q += d0 * d0 + d1 * d1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = xv[v][e] - mu;
+        q = fmaf(d, d, q);
+      }
     }
-    const float rs = rsqrtf(wave_sum(q) * invD + a.eps);
-    if (lane == 0) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rs = rsqrtf(q * invD + a.eps);
+    if (!live) continue;
+    if (l32 == 0) {
       if (a.mean) a.mean[r] = mu;
       if (a.rstd) a.rstd[r] = rs;
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const float y0 = (xv[v][0] - mu) * rs * gm[v][0] + bt[v][0];
-      const float y1 = (xv[v][1] - mu) * rs * gm[v][1] + bt[v][1];
-      const size_t o = (size_t)r * a.D + v * 128 + lane * 2;
+      const f32x4 y = (xv[v] - mu) * rs * gm[v] + bt[v];
+      const size_t o = (size_t)r * a.D + (v * 32 + l32) * 4;
       if (a.y_bf16) {
-        bf16x2 ob = {f2bf(y0), f2bf(y1)};
-        *(bf16x2*)(a.y_bf16 + o) = ob;
+        const bf16x4 ob = {f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
+        *(bf16x4*)(a.y_bf16 + o) = ob;
       }
-      if (a.y_f32) {
-        f32x2 of = {y0, y1};
-        *(f32x2*)(a.y_f32 + o) = of;
-      }
+      if (a.y_f32) *(f32x4*)(a.y_f32 + o) = y;
     }
   }
 }
@@ -230,7 +244,7 @@ extern "C" int devit_layernorm_fwd(const float* x, int rows, int D, int in_group
   DEVIT_CHECK(rows > 0 && D % 128 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE,
               "devit_layernorm_fwd: D=%d must be a multiple of 128, <= 1024", D);
   LnFwdArgs a{x, gamma, beta, (__bf16*)y_bf16, y_f32, mean, rstd, rows, D, in_group, in_stride, eps};
-  const int grid = rows < 4 * 2048 ? (rows + 3) / 4 : 2048;
+  const int grid = rows < 8 * 2048 ? (rows + 7) / 8 : 2048;   // 8 half-waves (rows in flight) per 256-thread block
   int rc = dispatch_nv<LnFwdArgs>(D, [&](auto nv) {
     hipLaunchKernelGGL((ln_fwd_kernel<decltype(nv)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   });
