@@ -64,9 +64,19 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* y, int M
   const int r0 = (int)((long long)M * chunk / nchunk), r1 = (int)((long long)M * (chunk + 1) / nchunk);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (col < N) {
-    for (int r = r0 + rl; r < r1; r += 8) {
-      const size_t pr = row_group > 0 ? (size_t)r + row_skip * (r / row_group + 1) : (size_t)r;
-      const bf16x8 v = *(const bf16x8*)(y + pr * ld + col);
+    auto prow = [&](int r) { return row_group > 0 ? (size_t)r + row_skip * (r / row_group + 1) : (size_t)r; };
+    int r = r0 + rl;
+    for (; r + 24 < r1; r += 32) {      // four independent 16-byte loads in flight per thread
+      bf16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = load_stream((const bf16x8*)(y + prow(r + 8 * u) * ld + col));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[u][e]);
+    }
+    for (; r < r1; r += 8) {
+      const bf16x8 v = *(const bf16x8*)(y + prow(r) * ld + col);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
     }

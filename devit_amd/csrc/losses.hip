@@ -157,15 +157,16 @@ __global__ __launch_bounds__(256) void rel_stats_kernel(const RelStatArgs a) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.B * a.N) return;
   const int b = row / a.N, i = row % a.N;
-  const float* rt = a.rt + ((size_t)b * a.ldr + i) * a.ldr;
-  const float* rs = a.rs + ((size_t)b * a.ldr + i) * a.ldr;
+  // one 16-byte load per lane and matrix: columns 4 lane .. 4 lane + 3 of the 256-wide padded Gram row
+  const f32x4 vt = lane * 4 < a.ldr ? *(const f32x4*)(a.rt + ((size_t)b * a.ldr + i) * a.ldr + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4 vs = lane * 4 < a.ldr ? *(const f32x4*)(a.rs + ((size_t)b * a.ldr + i) * a.ldr + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
   float t[4], s[4];
   float mt = -INFINITY, ms = -INFINITY;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int j = lane + k * 64;
-    t[k] = j < a.N ? rt[j] * a.inv_sqrt_t : -INFINITY;
-    s[k] = j < a.N ? rs[j] * a.inv_sqrt_s : -INFINITY;
+    const int j = lane * 4 + k;
+    t[k] = j < a.N ? vt[k] * a.inv_sqrt_t : -INFINITY;
+    s[k] = j < a.N ? vs[k] * a.inv_sqrt_s : -INFINITY;
     mt = fmaxf(mt, t[k]);
     ms = fmaxf(ms, s[k]);
   }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void rel_stats_kernel(const RelStatArgs a) {
   float kl = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (lane + k * 64 < a.N) {
+    if (lane * 4 + k < a.N) {
       const float a_t = t[k] - lt, a_s = s[k] - ls;
       kl += expf(a_t) * (a_t - a_s);
     }
@@ -227,19 +228,30 @@ struct RelGradArgs {
   float inv_sqrt_t, inv_sqrt_s, coef;  // coef = 1 / (B * sqrt(hd_s))
 };
 __global__ __launch_bounds__(256) void rel_grad_kernel(const RelGradArgs a) {
-  const int b = blockIdx.y, i = blockIdx.x;
-  const int j = threadIdx.x;  // ldr == 256
-  const size_t o = ((size_t)b * a.ldr + i) * a.ldr + j;
-  float v = 0.f;
-  if (i < a.N && j < a.N) {
+  // one wave per Gram row, four columns per lane: 16-byte loads of both Grams, one 8-byte (bf16) or 16-byte store
+  const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int j0 = (threadIdx.x & 63) * 4;  // ldr == 256
+  const size_t o = ((size_t)b * a.ldr + i) * a.ldr + j0;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (i < a.N) {
     const float up = (a.upstream ? *a.upstream : 1.0f) * a.coef;
-    const float rs = a.rs[o] * a.inv_sqrt_s, rt = a.rt[o] * a.inv_sqrt_t;
-    const float lsi = a.lse_s[b * a.N + i], lsj = a.lse_s[b * a.N + j];
-    const float lti = a.lse_t[b * a.N + i], ltj = a.lse_t[b * a.N + j];
-    v = (expf(rs - lsi) + expf(rs - lsj) - expf(rt - lti) - expf(rt - ltj)) * up;
+    const f32x4 rsv = *(const f32x4*)(a.rs + o), rtv = *(const f32x4*)(a.rt + o);
+    const float lsi = a.lse_s[b * a.N + i], lti = a.lse_t[b * a.N + i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      if (j < a.N) {
+        const float rs = rsv[e] * a.inv_sqrt_s, rt = rtv[e] * a.inv_sqrt_t;
+        const float lsj = a.lse_s[b * a.N + j], ltj = a.lse_t[b * a.N + j];
+        v[e] = (expf(rs - lsi) + expf(rs - lsj) - expf(rt - lti) - expf(rt - ltj)) * up;
+      }
+    }
   }
-  if (a.out_f32) ((float*)a.S)[o] = v;
-  else ((__bf16*)a.S)[o] = f2bf(v);
+  if (a.out_f32) *(f32x4*)((float*)a.S + o) = v;
+  else {
+    const bf16x4 ob = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *(bf16x4*)((__bf16*)a.S + o) = ob;
+  }
 }
 
 // ---- token MSE (nn.MSELoss, utils/losses.py:194,228,241-242): loss (+)= mean((a-b)^2), da = 2 (a-b) / n ---------
@@ -291,7 +303,8 @@ extern "C" int devit_relation_stats(const float* gram_t, const float* gram_s, in
                                     int head_dim_s, float* lse_t, float* lse_s, float* row_kl, float* loss,
                                     void* stream) {
   DEVIT_CHECK(gram_t && gram_s && lse_t && lse_s && row_kl && loss, DEVIT_ERR_ARG, "devit_relation_stats: null pointer");
-  DEVIT_CHECK(N > 0 && N <= 256 && ldr >= N, DEVIT_ERR_SHAPE, "devit_relation_stats: N=%d must be <= 256", N);
+  DEVIT_CHECK(N > 0 && N <= 256 && ldr >= N && ldr <= 256 && ldr % 4 == 0, DEVIT_ERR_SHAPE,
+              "devit_relation_stats: N=%d must be <= ldr=%d <= 256, ldr a multiple of 4", N, ldr);
   RelStatArgs a{gram_t, gram_s, lse_t, lse_s, row_kl, B, N, ldr, 1.0f / sqrtf((float)head_dim_t),
                 1.0f / sqrtf((float)head_dim_s)};
   hipLaunchKernelGGL(rel_stats_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
@@ -310,7 +323,7 @@ extern "C" int devit_relation_grad(const float* gram_t, const float* gram_s, con
   RelGradArgs a{gram_t, gram_s, lse_t, lse_s, upstream, S_out, B, N, ldr, out_is_f32,
                 1.0f / sqrtf((float)head_dim_t), 1.0f / sqrtf((float)head_dim_s),
                 1.0f / ((float)B * sqrtf((float)head_dim_s))};
-  hipLaunchKernelGGL(rel_grad_kernel, dim3(ldr, B), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(rel_grad_kernel, dim3(ldr / 4, B), dim3(256), 0, (hipStream_t)stream, a);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }
