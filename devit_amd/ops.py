@@ -238,10 +238,13 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, p
     M, H, dev = B * N, bp.num_heads, dx.device
     Hd = bp.fc1_w.shape[0]
     # ---- MLP branch: x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2)))
+    # Order: the weight gradient that only needs g2 first, then dh_pre's producer and its consumers back to back (dh_pre is
+    # 156 MB at B = 256; these GEMMs run 1.2-1.7x slower on operands from cold HBM than from the 256 MB Infinity Cache,
+    # tools/gemm_bench.py COLD=1; +0.6 % on the step)
+    linear_wgrad(g2, s["h"], grad_buf(bp.fc2_w), None if g2_bias_done else grad_buf(bp.fc2_b), M)
     dh_pre = rows_alloc(M, Hd, BF16, dev)
     linear_dgrad(g2, bp.fc2_w16, M, out=dh_pre, kind=L.EPI_DGELU_BF16, colscale=bp.neuron_gate, aux_in=s["h_pre"],
                  exact_gelu=cfg.exact_gelu)
-    linear_wgrad(g2, s["h"], grad_buf(bp.fc2_w), None if g2_bias_done else grad_buf(bp.fc2_b), M)
     dln2 = rows_alloc(M, D, BF16, dev)
     linear_dgrad(dh_pre, bp.fc1_w16, M, out=dln2)
     linear_wgrad(dh_pre, s["ln2"], grad_buf(bp.fc1_w), grad_buf(bp.fc1_b), M)

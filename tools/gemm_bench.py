@@ -10,7 +10,17 @@ M = 50688
 BF = torch.bfloat16
 def rnd(*s, dt=BF, std=1.0): return (torch.randn(*s, device=dev) * std).to(dt)
 
+COLD = os.environ.get("COLD", "0") == "1"     # flush the 256 MB Infinity Cache before every timed launch: in the step
+_big = torch.empty(320 << 20, dtype=torch.uint8, device=dev) if COLD else None   # the operands come from HBM
 def timeit(fn, reps=20):
+    if COLD:
+        fn(); best = 1e9
+        for _ in range(6):
+            _big.zero_(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3)
+        return best
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,4 +58,5 @@ for tag, D in (("S", 384), ("T", 768)):
         gk = torch.zeros(3 * D, D, device=dev)
         for sk in (9, 18, 37):
             report(f"S qkv wgrad split_k={sk:3d} [1152,384]", 2.0 * M * 3 * D * D, timeit(lambda: ops.gemm(o3, 3 * D, 1, x, D, 1, 3 * D, D, M, kind=L.EPI_ATOMIC_F32, out=gk, ldc=D, split_k=sk)))
+os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/gemm_bench.json", "w"))
