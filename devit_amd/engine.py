@@ -202,6 +202,37 @@ def train_1epoch_qkv(model, teacher_model, criterion, data_loader, optimizer, de
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 
+def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler, log=None, max_norm=0,
+                    model_ema=None, mixup_fn=None, print_freq=10):
+    """train_subdata.py:233-286: the plain (teacher-in-criterion) training loop that produces the sub-dataset teachers
+    and fine-tuned models -- `criterion` is losses.DistillationLoss(inputs, outputs, labels).  Same kernels as the DEKD
+    step; `.item()` only every print_freq steps (the reference syncs every step, :266,:279)."""
+    from .utils import MetricLogger, SmoothedValue
+    model.train(True)
+    metric_logger = MetricLogger(delimiter="  ")
+    metric_logger.add_meter('lr', SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    header = 'Epoch: [{}]'.format(epoch)
+    step = 0
+    for samples, targets, _ in metric_logger.log_every(_PreparedBatches(data_loader, device, mixup_fn, None), print_freq, header):
+        outputs = model(samples)                                                     # :258
+        loss = criterion(inputs=samples, outputs=outputs, labels=targets)            # :259
+        if step % print_freq == 0:
+            loss_value = loss.item()
+            if not math.isfinite(loss_value):                                        # :263-265
+                print("Loss is {}, stopping training".format(loss_value))
+                sys.exit(1)
+            metric_logger.update(loss=loss_value, lr=optimizer.param_groups[0]["lr"])
+        optimizer.zero_grad()
+        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters())
+        if model_ema is not None:
+            model_ema.update(model)
+        step += 1
+    metric_logger.synchronize_between_processes()
+    if log is not None:
+        log.info(f"Averaged stats: {metric_logger}")
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
 @torch.no_grad()
 def evaluate(data_loader, model, device):
     """engine.py:17-45: eval forward, CE, top-1 / top-5."""

@@ -106,6 +106,40 @@ def feature_relation_loss(teacher_feature, student_feature):
     return losses[0]
 
 
+class DistillationLoss(nn.Module):
+    """utils/losses.py:44-118 (DeiT's criterion, used by train_subdata.py:423-425): base criterion on the class-token
+    logits plus hard / soft distillation of the distillation-token logits against a teacher that is run INSIDE the
+    criterion, under no_grad, on the same inputs (:104-106); `(1 - alpha) * base + alpha * distill` (:115).
+    distillation_type 'none' returns the base loss (:100-101).  The distill_token variant (token MSE against the
+    teacher's last tokens, :107-112) needs --distillation-token / resize_dim, which is not on the DeViT path."""
+
+    def __init__(self, base_criterion, teacher_model, distillation_type, alpha, tau, distill_token=False):
+        super().__init__()
+        assert distillation_type in ['none', 'soft', 'hard']
+        if distill_token:
+            raise NotImplementedError("DistillationLoss(distill_token=True): resize_dim models are outside the DeViT path")
+        self.base_criterion, self.teacher_model = base_criterion, teacher_model
+        self.distillation_type, self.alpha, self.tau = distillation_type, alpha, tau
+        # LabelSmoothingCrossEntropy (train_subdata.py:411-416 without mixup) == soft-target CE on smoothed one-hot rows
+        self._smoothing = base_criterion.smoothing if isinstance(base_criterion, LabelSmoothingCrossEntropy) else None
+        fused = SoftTargetCrossEntropy() if self._smoothing is not None else base_criterion
+        self._loss = DistillLoss(fused, distillation_type, alpha, tau)
+
+    def forward(self, inputs, outputs, labels, token_outputs=None):
+        if self._smoothing is not None and labels.dtype in (torch.int64, torch.int32):
+            C = (outputs if isinstance(outputs, torch.Tensor) else outputs[0]).shape[-1]
+            labels = torch.full((labels.shape[0], C), self._smoothing / C, dtype=torch.float32, device=labels.device) \
+                .scatter_(1, labels.long()[:, None], 1.0 - self._smoothing + self._smoothing / C)
+        if self.distillation_type == 'none':
+            logits = outputs if isinstance(outputs, torch.Tensor) else outputs[0]
+            return self._loss((logits, logits), None, labels)
+        if isinstance(outputs, torch.Tensor):
+            raise ValueError("DistillationLoss: the model must return (outputs, outputs_kd) when distilling")
+        with torch.no_grad():
+            teacher_outputs = self.teacher_model(inputs)
+        return self._loss(outputs, teacher_outputs, labels)
+
+
 class LabelSmoothingCrossEntropy(nn.Module):
     """utils/losses.py:10-34; expressed through the fused kernel with smoothed one-hot targets."""
 

@@ -43,3 +43,52 @@ def test_ensemble_cli(tmp_path):
     import json
     line = json.loads(open(os.path.join(str(tmp_path), "log.txt")).read().splitlines()[-1])
     assert line["train_loss"] == line["train_loss"] and "test_acc1" in line
+
+
+@pytest.mark.parametrize("extra", [[], ["--distillation-type", "hard"], ["--mixup", "0", "--cutmix", "0", "--distillation-type", "soft"]])
+def test_train_subdata_cli(tmp_path, extra):
+    """train_subdata.py (teacher / fine-tuning loop, DistillationLoss with the teacher inside the criterion)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import train_subdata
+    parser = argparse.ArgumentParser(parents=[train_subdata.get_args_parser()], conflict_handler='resolve')
+    args = parser.parse_args(["--synthetic", "3", "--batch-size", "4", "--epochs", "1", "--model", "dedeit",
+                              "--teacher-model", "deit_base_distilled_patch16_224", "--dataset", "cifar100",
+                              "--num_division", "4", "--output_dir", str(tmp_path), "--warmup-epochs", "0"] + extra)
+    train_subdata.main(args)
+    out = os.path.join(str(tmp_path), "sub-dataset0")
+    import json
+    line = json.loads(open(os.path.join(out, "log.txt")).read().splitlines()[-1])
+    assert line["train_loss"] == line["train_loss"] and "test_acc1" in line
+    ck = torch.load(os.path.join(out, "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
+    assert len(ck["model"]) == 155
+
+
+def test_distillation_loss_equals_distill_loss():
+    """losses.DistillationLoss (teacher inside, utils/losses.py:44-118) == DistillLoss on the teacher's logits."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from devit_amd import losses
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    B, C = 8, 25
+    lo, lk, lt = (torch.randn(B, C, device=dev, requires_grad=r) for r in (True, True, False))
+    y = torch.randint(0, C, (B,), device=dev)
+
+    class T(torch.nn.Module):
+        def forward(self, x):
+            return lt
+    for kind in ("hard", "soft", "none"):
+        for base, ref_base in ((torch.nn.CrossEntropyLoss(), torch.nn.CrossEntropyLoss()),
+                               (losses.LabelSmoothingCrossEntropy(0.1), torch.nn.CrossEntropyLoss(label_smoothing=0.1))):
+            got = losses.DistillationLoss(base, T(), kind, 0.5, 2.0)(inputs=None, outputs=(lo, lk), labels=y)
+            b = ref_base(lo, y)
+            if kind == "none":
+                ref = b
+            elif kind == "hard":
+                ref = 0.5 * b + 0.5 * torch.nn.functional.cross_entropy(lk, lt.argmax(1))
+            else:
+                ref = 0.5 * b + 0.5 * torch.nn.functional.kl_div(torch.log_softmax(lk / 2, 1), torch.log_softmax(lt / 2, 1),
+                                                                 reduction="sum", log_target=True) * 4 / lk.numel()
+            assert abs(float(got) - float(ref)) < 1e-5 * abs(float(ref)), (kind, float(got), float(ref))
