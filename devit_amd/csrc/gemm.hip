@@ -2,8 +2,8 @@
 //
 // Tiles 128x128x64 (4 waves, two workgroups per CU) or 256x256x64 (8 waves), each wave a 64x64 / 128x64 sub-tile of
 // MFMA 16x16x32 accumulators.  Operand tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-// wave-instruction) into a ring of stages, one raw barrier per K-step with the newest stages still in flight
-// (counted vmcnt).  The LDS image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
+// wave-instruction) into a two-stage ring: the next stage is in flight while the current one is multiplied.  The
+// LDS image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
 // address and undone by the same XOR on the fragment read (cdna_hip_programming.md §5.4 rule 21): swz_row() for
 // k-contiguous operands (ds_read_b128 fragments), swz_krow() for k-major operands (ds_read_b64_tr_b16 fragments).
 // Epilogues run straight from the accumulators (epilogue_direct): the MFMAs take the weight operand on their row
@@ -89,7 +89,7 @@ __device__ __forceinline__ unsigned lane_offset(int ld, int wave, int lane, int 
 // address `lds`.  Inline asm on purpose: hipcc's waitcnt pass treats a builtin LDS-DMA as a pending LDS write and
 // guards later ds_reads with `s_waitcnt vmcnt(0)` whenever it cannot prove the buffers distinct -- which serialises
 // the ring (observed: every K-step of some instantiations, every tile boundary of all).  Hidden in asm, the DMA is
-// ordered by this kernel's own counted vmcnt + barrier (advance()); hipcc's counts for its own loads/stores stay
+// ordered by this kernel's own vmcnt wait + barrier (advance()); hipcc's counts for its own loads/stores stay
 // safe because they can only be stricter with extra operations in the queue.  M0 (the DMA's LDS base) is saved and
 // restored around the statement; the padding covers SGPR-write -> VMEM-read and M0-write -> LDS-DMA wait states
 // (cdna_hip_programming.md §5.7).
@@ -393,9 +393,7 @@ __device__ __forceinline__ TileRef decode_tile(const GemmArgs& g, int w) {
 // filled by LDS-DMA.  A workgroup walks its share of the output tiles and treats their K-steps as ONE stream of ring
 // stages: the refill issued during the last K-steps of a tile already belongs to the next tile, so neither the
 // DMA latency of a tile's first stages nor the register-only epilogue leaves the ring empty.  One raw barrier per
-// K-step; the DMA of the newest stages stays in flight across it (counted vmcnt -- the count names the DMA
-// instructions issued after the stage being waited for; epilogue stores queued in between only make the wait
-// stricter, never unsafe, because vmcnt retires in order).
+// K-step (128x128) or the four-interval ping-pong schedule below (256x256).
 // Tile order: workgroups b, b+8, ... share an XCD (and its L2); each XCD owns a contiguous run of tiles (n-tile
 // fastest inside an L2-sized chunk of B, see decode_tile) and its workgroups walk that run side by side.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool A_KM, bool B_KM, int KIND>
@@ -405,7 +403,7 @@ void gemm_kernel(const GemmArgs g) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
   static_assert(WN == 64 && WM % 64 == 0, "wave tile must be (64 k) x 64");
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+  static_assert(NSTAGE == 2, "two-stage ring (deeper rings at one workgroup per CU lost everywhere)");
   // Every epilogue but the split-K atomic one runs straight from the accumulators: the MFMAs then take the B operand
   // (output columns) on their row side, see epilogue_direct().  The atomic one stages through the ring's LDS, so its
   // stream stops at every tile end.
@@ -413,7 +411,6 @@ void gemm_kernel(const GemmArgs g) {
   constexpr bool PAIRED = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
   constexpr int A_TILE_BYTES = BM * BK * 2, B_TILE_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
-  constexpr int PER = (BM / 8 + BN / 8) / NWAVES;  // LDS-DMA instructions per wave per stage
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -431,7 +428,7 @@ void gemm_kernel(const GemmArgs g) {
 
   // producer cursor: the next ring stage to request
   TileRef pt = decode_tile<BM, BN, A_KM, B_KM>(g, first);
-  int p_tile = first, p_t = 0, p_slot = 0, inflight = 0;
+  int p_tile = first, p_t = 0, p_slot = 0;
   bool p_open = true;                                   // false: nothing (more) to request right now
   auto produce = [&]() {
     char* buf = smem + p_slot * STAGE_BYTES;
@@ -444,8 +441,7 @@ void gemm_kernel(const GemmArgs g) {
 #ifdef DEVIT_GEMM_NODMA
     }
 #endif
-    p_slot = p_slot + 1 == NSTAGE ? 0 : p_slot + 1;
-    ++inflight;
+    p_slot ^= 1;
     if (++p_t == pt.nk) {
       p_t = 0;
       p_tile += stride;
@@ -525,18 +521,14 @@ void gemm_kernel(const GemmArgs g) {
     return;
   }
 
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (p_open) produce();
+  produce();   // first stage of the first tile
 
-  // Make the oldest stage in flight readable: it must have landed (the ones requested after it may stay in flight),
-  // every wave must know so and must have finished reading the slot the refill overwrites (the one read a step ago).
+  // Make the stage in flight readable: it must have landed, every wave must know so and must have finished reading the
+  // slot the refill overwrites (the one read a step ago).
   auto advance = [&]() {
-    if (NSTAGE == 3 && inflight == 2) wait_vmcnt<PER>();
-    else wait_vmcnt<0>();
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (p_open) produce();
-    --inflight;
   };
 
   int c_slot = 0;
@@ -551,7 +543,7 @@ void gemm_kernel(const GemmArgs g) {
 
     auto kstep = [&]() {
       const char* cur = smem + c_slot * STAGE_BYTES;
-      c_slot = c_slot + 1 == NSTAGE ? 0 : c_slot + 1;
+      c_slot ^= 1;
 #ifdef DEVIT_GEMM_NOCOMPUTE   // diagnostic build: the fill pipeline alone
       if (g.K < 0)
 #endif
@@ -597,7 +589,7 @@ void gemm_kernel(const GemmArgs g) {
     } else {
       // split-K partial sums: accumulators -> this wave's private 64x64 f32 LDS tile -> one atomic per element, 64
       // consecutive floats per instruction; one pass per 64 rows of the wave tile.  The ring is empty here
-      // (inflight == 0: the stream stops at tile ends for this kind).
+      // (the stream stops at tile ends for this kind).
       __syncthreads();  // all fragment reads done before the ring is reused as the staging area
       float* cw = (float*)smem + wave * 4096;
       float* out = (float*)ep.out + ob;
@@ -624,9 +616,7 @@ void gemm_kernel(const GemmArgs g) {
         pt = decode_tile<BM, BN, A_KM, B_KM>(g, p_tile);
         p_open = true;
         p_slot = c_slot;
-#pragma unroll
-        for (int s = 0; s < NSTAGE - 1; ++s)
-          if (p_open) produce();
+        produce();
       }
     }
   }
@@ -674,27 +664,23 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   g.M = M; g.N = N; g.K = K;
   g.tiles_m = 0; g.tiles_n = 0; g.split_k = split_k;
   g.ep = *ep;
-  // tile choice: 256x256 (8 waves of 128x64, 2-deep ring) when both dims allow, else 256x128 (8 waves of
-  // 64x64, 3-deep ring), else 128x128 (4 waves)
+  // tile choice: 128x128 (4 waves, two workgroups per CU) or 256x256 (8 waves of 128x64, ping-pong schedule, one per CU)
   const int variant = (a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0);
-  static const int force = getenv("DEVIT_GEMM_TILE") ? atoi(getenv("DEVIT_GEMM_TILE")) : 0;  // 1: 128x128, 2: 256x128
   // Measured on the step's shapes (tools/gemm_tiles.py + tools/gpu_tiles.sh, M = 50688, TFLOP/s 256x256 vs 128x128):
   // the ping-pong 256x256 tile wins the long-K and plain-store shapes (teacher qkv 915-950 vs 838, fc2 K 3072 786 vs
   // 778) and the VALU-heavy GELU / dGELU epilogues at any K (student fc1 484 vs 452, teacher fc1 842 vs 817, fc2
   // dgrad 499 vs 481: one wave of each SIMD pair keeps the MFMA pipe while the other is in its epilogue only with two
   // workgroups per CU, but the fused GELU now costs less than the tile's extra fill traffic); the fp32 residual
   // epilogue at K <= 768 stays on 128x128 (teacher proj 458 vs 442), as does everything whose N is not a multiple
-  // of 256 and the split-K wgrads.  256x128 won nowhere (kept for experiments).
+  // of 256 and the split-K wgrads.  (A 256x128 tile with a 3-deep ring and a 128x128 tile with a 3-deep ring at one
+  // workgroup per CU were built and lost on every shape, warm and cold; they are gone.)
   const bool light_epi = ep->kind == DEVIT_EPI_STORE_BF16 || ep->kind == DEVIT_EPI_STORE_F32;
   const bool gelu_epi = ep->kind == DEVIT_EPI_GELU_BF16 || ep->kind == DEVIT_EPI_DGELU_BF16;
   int cfg = 1;
   if (M % 256 == 0 && N % 256 == 0 && (K >= 1536 || (K >= 768 && light_epi) || gelu_epi) && variant != 3) cfg = 3;
-  static const int wg_cfg = getenv("DEVIT_GEMM_WGRAD_TILE") ? atoi(getenv("DEVIT_GEMM_WGRAD_TILE")) : 0;
-  if (variant == 3 && wg_cfg > 0) cfg = wg_cfg;
-  if (force > 0 && force < cfg) cfg = force;
-  static const int exact = getenv("DEVIT_GEMM_FORCE") ? atoi(getenv("DEVIT_GEMM_FORCE")) : 0;   // experiments
-  if (exact == 1 || (exact == 2 && M % 256 == 0) || (exact == 3 && M % 256 == 0 && N % 256 == 0 && variant != 3)) cfg = exact;
-  const int bm = cfg == 1 ? 128 : 256, bn = cfg == 3 ? 256 : 128;
+  static const int exact = getenv("DEVIT_GEMM_FORCE") ? atoi(getenv("DEVIT_GEMM_FORCE")) : 0;   // tools/gpu_tiles.sh
+  if (exact == 1 || (exact == 3 && M % 256 == 0 && N % 256 == 0 && variant != 3)) cfg = exact;
+  const int bm = cfg == 1 ? 128 : 256, bn = bm;
   g.tiles_m = M / bm;
   g.tiles_n = N / bn;
   {
@@ -769,7 +755,6 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
     }                                                                                                          \
   } while (0)
   if (cfg == 3) DEVIT_LAUNCH_GEMM(256, 256, 2, 4, 2);
-  else if (cfg == 2) DEVIT_LAUNCH_GEMM(256, 128, 4, 2, 3);
   else DEVIT_LAUNCH_GEMM(128, 128, 2, 2, 2);
 #undef DEVIT_LAUNCH_ONE
 #undef DEVIT_LAUNCH_GEMM
