@@ -396,16 +396,43 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
       }
     }
   }
-  // ---- dK, dV of this wave's key tiles: lane = key, 4 consecutive d per register quad
+  // ---- dK, dV of this wave's key tiles.  The accumulators hold 4 consecutive d per register quad for key = lane & 15:
+  // stored directly that is 8 bytes per lane in 32-byte row segments.  The images are dead now, so each wave turns its
+  // tiles around through a private LDS slab ([16 keys][64 d] fp32, padded rows) and writes -- and reads the
+  // optional extra gradient -- in whole 128-byte rows, 16 bytes per lane.
+  __syncthreads();                                   // every wave has finished reading the images
+  {
+    constexpr int SROW = 272;                        // bytes per staged key row: 64 fp32 + 16 B pad (conflict-free writes)
+    char* slab = smem + wave * (2 * 16 * SROW);      // [dk | dv] x 16 rows, fp32: rounded to bf16 once, after the add
 #pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    const int kt = wave + t * BWD_WAVES, key = kt * 16 + lc;
-    if (kt < ntile && key < N) {
+    for (int t = 0; t < KT; ++t) {
+      const int kt = wave + t * BWD_WAVES;
+      if (kt >= ntile) break;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const size_t o = ((size_t)b * N + key) * rs + h * HD + dt * 16 + g * 4;
-        store_grad4(a.dqkv + o + D, a.dqkv_add ? a.dqkv_add + o + D : nullptr, dk[t][dt]);
-        store_grad4(a.dqkv + o + 2 * D, a.dqkv_add ? a.dqkv_add + o + 2 * D : nullptr, dv[t][dt]);
+        *(f32x4*)(slab + lc * SROW + (dt * 16 + g * 4) * 4) = dk[t][dt];
+        *(f32x4*)(slab + 16 * SROW + lc * SROW + (dt * 16 + g * 4) * 4) = dv[t][dt];
+      }
+      // (same wave writes and reads: the LDS queue is in order and hipcc waits lgkmcnt before the reads' use)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = half * 8 + (lane >> 3), c8 = lane & 7, key = kt * 16 + row;
+        if (key < N) {
+          const size_t o = ((size_t)b * N + key) * rs + h * HD + c8 * 8;
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {            // 0: dK (+D), 1: dV (+2D)
+            const char* src = slab + which * 16 * SROW + row * SROW + c8 * 32;
+            f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
+            const size_t oo = o + (which + 1) * (size_t)D;
+            if (a.dqkv_add) {
+              const bf16x8 e = *(const bf16x8*)(a.dqkv_add + oo);
+              lo += (f32x4){bf2f(e[0]), bf2f(e[1]), bf2f(e[2]), bf2f(e[3])};
+              hi += (f32x4){bf2f(e[4]), bf2f(e[5]), bf2f(e[6]), bf2f(e[7])};
+            }
+            const bf16x8 v = {f2bf(lo[0]), f2bf(lo[1]), f2bf(lo[2]), f2bf(lo[3]), f2bf(hi[0]), f2bf(hi[1]), f2bf(hi[2]), f2bf(hi[3])};
+            *(bf16x8*)(a.dqkv + oo) = v;
+          }
+        }
       }
     }
   }

@@ -282,6 +282,15 @@ def test_attention_fwd_bwd(dev, B, N, H):
          stream_ptr())
     err = relerr(dqkv[:M], q32.grad)
     assert err < 2e-2, f"dqkv rel-to-max err {err:.3e}"    # bf16 P / dS operands: ~2^-8 relative
+    # extra gradient added into dqkv (relation loss on the middle block): one rounding, after the fp32 add
+    add = ops.rows_alloc(M, 3 * D, BF16, dev)
+    add[:M] = rnd((M, 3 * D), dev, 0.5, seed=11, dtype=BF16)
+    dqkv2 = ops.rows_alloc(M, 3 * D, BF16, dev)
+    call("devit_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(gate), ptr(add), ptr(dqkv2), B, N, H, 64, 0.125,
+         stream_ptr())
+    err2 = relerr(dqkv2[:M], q32.grad + add[:M].float())
+    assert err2 < 2e-2, f"dqkv + add rel-to-max err {err2:.3e}"
+    bf16_ulp_ok(dqkv2[:M], dqkv[:M].float() + add[:M].float(), extra=2e-3)
 
 
 # ------------------------------------------------------------------------------------------ elementwise
