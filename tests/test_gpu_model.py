@@ -320,3 +320,33 @@ def test_compacted_model_equals_masked_model(models, dev):
         for blk in s.blocks:
             blk.attn.gate, blk.mlp.gate = torch.ones(6), torch.ones(1536)
         s.train()
+
+
+# ------------------------------------------------------------------------------------------ non-distilled geometry
+def test_nondistilled_devit_vs_oracle(dev):
+    """`devit` (one class token, 197 token rows per image, tensor output in both modes; models/de_vit.py:495-513) at a
+    ragged batch (3 images -> 591 rows, padded to 768): eval logits and a full backward against the CPU oracle's
+    autograd."""
+    import devit_amd
+    geom = O.GEOMETRY["devit"]
+    st = O.make_state(geom, C, "V")
+    m = devit_amd.create_model("devit", num_classes=C, drop_path_rate=0.0).to(dev)
+    m.load_state_dict(st)
+    img = torch.from_numpy(det_array("devit", (3, 3, 224, 224), std=0.7))
+    y = torch.tensor([3, 17, 8])
+    st_g = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+    ref = O.forward(st_g, geom, img, training=True)["output"]
+    assert isinstance(ref, torch.Tensor) and ref.shape == (3, C)
+    torch.nn.functional.cross_entropy(ref, y).backward()
+    m.eval()
+    with torch.no_grad():
+        out_eval = m(img.to(dev))
+    assert rel(out_eval, ref.detach().numpy()) < 3e-2 and torch.equal(out_eval.argmax(1).cpu(), ref.argmax(1))
+    m.train()
+    out = m(img.to(dev))
+    assert isinstance(out, torch.Tensor)
+    torch.nn.functional.cross_entropy(out.float(), y.to(dev)).backward()
+    for name, p in m.named_parameters():
+        g_ref = st_g[name].grad
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+        assert rel(p.grad, g_ref.numpy()) < 8e-2, (name, rel(p.grad, g_ref.numpy()))
