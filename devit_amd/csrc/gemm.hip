@@ -389,7 +389,7 @@ __device__ __forceinline__ TileRef decode_tile(const GemmArgs& g, int w) {
   return t;
 }
 
-// Persistent BM x BN x 64 GEMM: WAVES_M x WAVES_N waves (each (BM/WAVES_M) x (BN/WAVES_N)), NSTAGE-deep LDS ring
+// Persistent BM x BN x 64 GEMM: WAVES_M x WAVES_N waves (each (BM/WAVES_M) x (BN/WAVES_N)), LDS ring (3 A + 2 B slots)
 // filled by LDS-DMA.  A workgroup walks its share of the output tiles and treats their K-steps as ONE stream of ring
 // stages: the refill issued during the last K-steps of a tile already belongs to the next tile, so neither the
 // DMA latency of a tile's first stages nor the register-only epilogue leaves the ring empty.  One raw barrier per
@@ -403,14 +403,21 @@ void gemm_kernel(const GemmArgs g) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
   static_assert(WN == 64 && WM % 64 == 0, "wave tile must be (64 k) x 64");
-  static_assert(NSTAGE == 2, "two-stage ring (deeper rings at one workgroup per CU lost everywhere)");
+  static_assert(NSTAGE == 2, "NSTAGE is the B ring depth; uniformly deeper rings at one workgroup per CU lost everywhere");
   // Every epilogue but the split-K atomic one runs straight from the accumulators: the MFMAs then take the B operand
   // (output columns) on their row side, see epilogue_direct().  The atomic one stages through the ring's LDS, so its
   // stream stops at every tile end.
   constexpr bool DIRECT = KIND != DEVIT_EPI_ATOMIC_F32;
   constexpr bool PAIRED = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
   constexpr int A_TILE_BYTES = BM * BK * 2, B_TILE_BYTES = BN * BK * 2;
-  constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+  // Ring: two B slots, THREE A slots.  A is the operand that streams from HBM (an activation; B is a weight that lives in
+  // L2 -- or, in the weight-gradient GEMMs, the narrower activation), so its stages are requested one K-step earlier:
+  // two A stages in flight per workgroup at unchanged occupancy (128x128: 2 x 80 KB, 256x256: 160 KB = the whole LDS).
+  // Cold-HBM operands: +4...12 % on the 128x128 shapes (tools/gemm_bench.py COLD=1), -1...3 % on cache-resident ones.
+  constexpr bool PP = DIRECT && BM == 256 && BN == 256 && WAVES_M == 2;   // ping-pong schedule, below
+  constexpr int NA = 3;                                          // A slots (B has 2)
+  constexpr int PER_A = (BM / 8) / NWAVES;                       // LDS-DMA instructions per wave per A stage
+  constexpr int B_RING = NA * A_TILE_BYTES;                      // LDS offset of the B slots
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -426,28 +433,58 @@ void gemm_kernel(const GemmArgs g) {
   }
   if (first >= last) return;
 
-  // producer cursor: the next ring stage to request
-  TileRef pt = decode_tile<BM, BN, A_KM, B_KM>(g, first);
-  int p_tile = first, p_t = 0, p_slot = 0;
-  bool p_open = true;                                   // false: nothing (more) to request right now
-  auto produce = [&]() {
-    char* buf = smem + p_slot * STAGE_BYTES;
+  // producer cursors: the next B stage to request (p) and, on the 3-slot A ring, the next A stage (q = p + 1 stage)
+  struct Cursor {
+    TileRef ref;
+    int tile, t;
+    bool open;
+  };
+  Cursor pb{decode_tile<BM, BN, A_KM, B_KM>(g, first), first, 0, true};
+  Cursor pa = pb;
+  int a_slot = 0, b_slot = 0;
+  bool a_last = false;   // the newest vector-memory operations of this wave are the PER_A DMAs of an A stage
+  auto step_cursor = [&](Cursor& c) {
+    if (++c.t == c.ref.nk) {
+      c.t = 0;
+      c.tile += stride;
+      if (DIRECT && c.tile < last) c.ref = decode_tile<BM, BN, A_KM, B_KM>(g, c.tile);
+      else c.open = false;
+    }
+  };
+  auto dma_a = [&](const Cursor& c) {
 #ifdef DEVIT_GEMM_NODMA       // diagnostic build: MFMAs + LDS reads alone (operands are whatever the LDS holds)
-    if (g.K >= 0) buf = nullptr;
-    if (buf != nullptr) {
+    if (g.K < 0)
 #endif
-    stage_tile<A_KM, BM, NWAVES>(pt.a, g.lda, (pt.kt0 + p_t) * BK, g.a_group, g.a_skip, buf, wave, lane);
-    stage_tile<B_KM, BN, NWAVES>(pt.b, g.ldb, (pt.kt0 + p_t) * BK, g.b_group, g.b_skip, buf + A_TILE_BYTES, wave, lane);
+    stage_tile<A_KM, BM, NWAVES>(c.ref.a, g.lda, (c.ref.kt0 + c.t) * BK, g.a_group, g.a_skip, smem + a_slot * A_TILE_BYTES,
+                                 wave, lane);
+    a_slot = a_slot + 1 == NA ? 0 : a_slot + 1;
+  };
+  auto dma_b = [&](const Cursor& c) {
 #ifdef DEVIT_GEMM_NODMA
-    }
+    if (g.K < 0)
 #endif
-    p_slot ^= 1;
-    if (++p_t == pt.nk) {
-      p_t = 0;
-      p_tile += stride;
-      if (DIRECT && p_tile < last) pt = decode_tile<BM, BN, A_KM, B_KM>(g, p_tile);
-      else p_open = false;
+    stage_tile<B_KM, BN, NWAVES>(c.ref.b, g.ldb, (c.ref.kt0 + c.t) * BK, g.b_group, g.b_skip,
+                                 smem + B_RING + b_slot * B_TILE_BYTES, wave, lane);
+    b_slot ^= 1;
+  };
+  auto issue_a = [&]() {
+    a_last = pa.open;
+    if (!pa.open) return;
+    dma_a(pa);
+    step_cursor(pa);
+  };
+  // One refill: B of the next stage first, then A of the stage after it.  The A request is the newest thing in the queue, so "everything but PER_A operations has completed"
+  // (wait_stage) means: the stage about to be read has landed, the A stage after it may still be in flight.
+  auto produce = [&]() {
+    if (pb.open) {
+      dma_b(pb);
+      step_cursor(pb);
     }
+    issue_a();
+  };
+  auto wait_stage = [&]() {
+    if (a_last) wait_vmcnt<PER_A>();
+    else wait_vmcnt<0>();
   };
   // ---------------------------------------------------------------------------------------------------------------
   // Ping-pong schedule (256x256 tile: the two waves of a SIMD are wm = 0 and wm = 1 of the SAME workgroup).  With one
@@ -456,14 +493,14 @@ void gemm_kernel(const GemmArgs g) {
   // the DMA removed.  Here a K-step is four barrier intervals -- reads(kk=0) | MFMA(0) | reads(1) | MFMA(1) -- and the
   // wm = 1 waves run ONE interval behind the wm = 0 waves (one extra barrier before a tile's first K-step, one extra
   // for wm = 0 after its last): in every interval one wave of each SIMD issues its 32 MFMAs while the other reads its next fragments.
-  //   interval a: request stage t+1 (overwrites the slot read in step t-1), ds_read fragments kk = 0, lgkmcnt(0)
+  //   interval a: request B of stage t+1 and A of stage t+2 (the slots read in step t-1), ds_read fragments kk = 0, lgkmcnt(0)
   //   interval b: MFMA kk = 0
-  //   interval c: ds_read fragments kk = 1, lgkmcnt(0), vmcnt(0) (this wave's share of stage t+1 has landed)
+  //   interval c: ds_read fragments kk = 1, lgkmcnt(0), counted vmcnt (this wave's share of stage t+1 has landed)
   //   interval d: MFMA kk = 1
   // RAW: a wave reads stage t+1 after its barrier Y1(t); the lagging group passed its own vmcnt(0) before its X1(t),
   // which is the same barrier event.  WAR: stage t+1's slot was last read in interval c of step t-1, retired by the
   // lgkmcnt(0) in front of X1(t-1), at least one barrier event before any wave requests stage t+1.
-  if constexpr (DIRECT && BM == 256 && BN == 256 && NSTAGE == 2 && WAVES_M == 2) {
+  if constexpr (PP) {
     auto fence = [&]() {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -473,10 +510,11 @@ void gemm_kernel(const GemmArgs g) {
       __builtin_amdgcn_s_barrier();
       fence();
     };
-    produce();                         // stage 0 of the first tile
+    issue_a();                         // A of stage 0, then B of stage 0 and A of stage 1
+    produce();
     wait_vmcnt<0>();
     bar();
-    int c_slot = 0;
+    int ca_slot = 0, cb_slot = 0;
     for (int tile = first; tile < last; tile += stride) {
       const TileRef ct = decode_tile<BM, BN, A_KM, B_KM>(g, tile);
       f32x4 acc[MI][NI];
@@ -490,18 +528,20 @@ void gemm_kernel(const GemmArgs g) {
       f32x4 bias[4], cs[4];
       if (wm == 1) bar();              // the offset: this group now runs one interval behind
       for (int t = 0; t < ct.nk; ++t) {
-        const char* cur = smem + c_slot * STAGE_BYTES;
-        c_slot ^= 1;
-        if (p_open) produce();
+        const char* cur_a = smem + ca_slot * A_TILE_BYTES;
+        const char* cur_b = smem + B_RING + cb_slot * B_TILE_BYTES;
+        ca_slot = ca_slot + 1 == NA ? 0 : ca_slot + 1;
+        cb_slot ^= 1;
+        produce();                     // B of stage t+1, A of stage t+2
         if (t == ct.nk - 1) load_cols<KIND>(ep, lane, nw, noff, bias, cs);   // under the last K-step
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           bf16x8 af[MI], bfr[NI];
 #pragma unroll
-          for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN, PAIRED>(cur + A_TILE_BYTES, wn * WN, j, kk, lane);
+          for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN, PAIRED>(cur_b, wn * WN, j, kk, lane);
 #pragma unroll
-          for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM, false>(cur, wm * WM, i, kk, lane);
-          if (kk == 1) wait_vmcnt<0>();
+          for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM, false>(cur_a, wm * WM, i, kk, lane);
+          if (kk == 1) wait_stage();   // stage t+1 has landed; A of stage t+2 may stay in flight
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           bar();
 #pragma unroll
@@ -521,17 +561,18 @@ void gemm_kernel(const GemmArgs g) {
     return;
   }
 
-  produce();   // first stage of the first tile
+  issue_a();   // A of the first stage, then B of the first stage and A of the second
+  produce();
 
-  // Make the stage in flight readable: it must have landed, every wave must know so and must have finished reading the
-  // slot the refill overwrites (the one read a step ago).
+  // Make the next stage readable: it must have landed, every wave must know so and must have finished reading the
+  // slots the refill overwrites (the ones read a step ago).
   auto advance = [&]() {
-    wait_vmcnt<0>();
+    wait_stage();
     __builtin_amdgcn_s_barrier();
-    if (p_open) produce();
+    produce();
   };
 
-  int c_slot = 0;
+  int ca_slot = 0, cb_slot = 0;
   bool primed = false;   // the stage at c_slot is already readable (advance() ran for it before the last epilogue)
   for (int tile = first; tile < last; tile += stride) {
     const TileRef ct = decode_tile<BM, BN, A_KM, B_KM>(g, tile);
@@ -542,8 +583,10 @@ void gemm_kernel(const GemmArgs g) {
       for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto kstep = [&]() {
-      const char* cur = smem + c_slot * STAGE_BYTES;
-      c_slot ^= 1;
+      const char* cur_a = smem + ca_slot * A_TILE_BYTES;
+      const char* cur_b = smem + B_RING + cb_slot * B_TILE_BYTES;
+      ca_slot = ca_slot + 1 == NA ? 0 : ca_slot + 1;
+      cb_slot ^= 1;
 #ifdef DEVIT_GEMM_NOCOMPUTE   // diagnostic build: the fill pipeline alone
       if (g.K < 0)
 #endif
@@ -551,9 +594,9 @@ void gemm_kernel(const GemmArgs g) {
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 af[MI], bfr[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN, PAIRED>(cur + A_TILE_BYTES, wn * WN, j, kk, lane);
+        for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN, PAIRED>(cur_b, wn * WN, j, kk, lane);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM, false>(cur, wm * WM, i, kk, lane);
+        for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM, false>(cur_a, wm * WM, i, kk, lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -611,11 +654,15 @@ void gemm_kernel(const GemmArgs g) {
       };
       do_pass(std::integral_constant<int, 0>());
       if constexpr (MI > 4) do_pass(std::integral_constant<int, 1>());
-      if (p_tile < last) {           // restart the stream on the next tile
+      if (pb.tile < last) {          // restart the stream on the next tile
         __syncthreads();             // every wave's staging reads done before the DMA overwrites them
-        pt = decode_tile<BM, BN, A_KM, B_KM>(g, p_tile);
-        p_open = true;
-        p_slot = c_slot;
+        pb.ref = decode_tile<BM, BN, A_KM, B_KM>(g, pb.tile);
+        pb.t = 0;
+        pb.open = true;
+        pa = pb;
+        a_slot = ca_slot;
+        b_slot = cb_slot;
+        issue_a();
         produce();
       }
     }
@@ -723,7 +770,7 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   hipStream_t s = (hipStream_t)stream;
 #define DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_)                                          \
   do {                                                                                                         \
-    constexpr int ring = NS_ * (BM_ + BN_) * 128, stagebytes = WMM_ * WNN_ * 16384;                            \
+    constexpr int ring = (3 * BM_ + 2 * BN_) * 128, stagebytes = WMM_ * WNN_ * 16384;                             \
     constexpr int lds = (KIND_ == DEVIT_EPI_ATOMIC_F32 && stagebytes > ring) ? stagebytes : ring;              \
     static bool attr = false;                                                                                  \
     if (!attr) {                                                                                               \
