@@ -146,35 +146,40 @@ __global__ __launch_bounds__(256) void embed_bwd_tail_kernel(const float* dpos, 
 }
 
 // ---- small strided f32 GEMM: C[m][n] = sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] (+ bias[n]) ------------
-// classifier heads (models/de_vit.py:317) and their backward; exact f32 FMA chain.
+// classifier heads (models/de_vit.py:317) and their backward.  Eight lanes per output element, lane p taking
+// k = p, p + 8, ... (adjacent lanes read adjacent k: 32-byte pieces of both operand rows), eight independent loads in
+// flight per operand and trip, fp32 fmaf partial sums combined by three xor-shuffles.  (One thread per output with a
+// serial K loop was a 48 us latency chain at 6400 outputs x K = 384: 25 workgroups on a 256-CU device.)
 __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* A, long long sam, long long sak, const float* B,
                                                           long long sbn, long long sbk, const float* bias, float* C,
                                                           int ldc, int M, int N, int K, float alpha, int accumulate) {
   const long long total = (long long)M * N;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int n = (int)(idx % N), m = (int)(idx / N);
+  const int part = threadIdx.x & 7;
+  for (long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3; idx < ((total + 31) & ~31ll);
+       idx += ((long long)gridDim.x * 256) >> 3) {
+    const bool live = idx < total;                       // whole waves stay in the loop: the shuffles need every lane
+    const long long id = live ? idx : total - 1;
+    const int n = (int)(id % N), m = (int)(id / N);
     const float* a = A + m * sam;
     const float* b = B + n * sbn;
     float s = 0.f;
-    int k = 0;
-    for (; k + 32 <= K; k += 32) {     // 64 independent loads in flight (the kernel is one load latency per trip: K / 8
-      float av[32], bv[32];            // trips took 49 us at K = 384), then the fmaf chain in k order
-#pragma unroll
-      for (int u = 0; u < 32; ++u) { av[u] = a[(k + u) * sak]; bv[u] = b[(k + u) * sbk]; }
-#pragma unroll
-      for (int u = 0; u < 32; ++u) s = fmaf(av[u], bv[u], s);
-    }
-    for (; k + 8 <= K; k += 8) {       // 16 independent loads in flight, then the fmaf chain in k order
+    int k = part;
+    for (; k + 56 < K; k += 64) {
       float av[8], bv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { av[u] = a[(k + u) * sak]; bv[u] = b[(k + u) * sbk]; }
+      for (int u = 0; u < 8; ++u) { av[u] = a[(k + 8 * u) * sak]; bv[u] = b[(k + 8 * u) * sbk]; }
 #pragma unroll
       for (int u = 0; u < 8; ++u) s = fmaf(av[u], bv[u], s);
     }
-    for (; k < K; ++k) s = fmaf(a[k * sak], b[k * sbk], s);
-    s = s * alpha + (bias ? bias[n] : 0.f);
-    float* c = C + (size_t)m * ldc + n;
-    *c = accumulate ? *c + s : s;
+    for (; k < K; k += 8) s = fmaf(a[k * sak], b[k * sbk], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (live && part == 0) {
+      s = s * alpha + (bias ? bias[n] : 0.f);
+      float* c = C + (size_t)m * ldc + n;
+      *c = accumulate ? *c + s : s;
+    }
   }
 }
 
@@ -327,7 +332,7 @@ extern "C" int devit_sgemm_small(const float* A, long long sam, long long sak, c
                                  long long sbk, const float* bias, float* C, int ldc, int M, int N, int K, float alpha,
                                  int accumulate, void* stream) {
   DEVIT_CHECK(A && B && C && M > 0 && N > 0 && K > 0, DEVIT_ERR_ARG, "devit_sgemm_small: bad argument");
-  hipLaunchKernelGGL(sgemm_small_kernel, dim3(grid_for((size_t)M * N, 8192)), dim3(256), 0, (hipStream_t)stream, A, sam,
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3(grid_for((size_t)M * N * 8, 8192)), dim3(256), 0, (hipStream_t)stream, A, sam,
                      sak, B, sbn, sbk, bias, C, ldc, M, N, K, alpha, accumulate);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
