@@ -17,6 +17,9 @@
 namespace {
 
 constexpr int BK = 64;
+#ifndef DEVIT_RAGGED_MIN_K
+#define DEVIT_RAGGED_MIN_K 768
+#endif
 
 // n / d for 0 <= n < 2^31 by multiply-shift (Granlund-Montgomery round-up): three SALU ops instead of the
 // float-reciprocal sequence hipcc emits for a scalar division.  Host-initialised.
@@ -70,18 +73,20 @@ __device__ __forceinline__ int swz_krow(int krow) { return ((krow & 3) << 2) | (
 // The address is split into a wave-uniform base that advances with k0 (SGPRs) and a per-lane 32-bit byte offset
 // that is loop-invariant, so the K-loop issues `global_load_lds_dwordx4 voff, s[base]` with no per-step VALU math.
 template <bool KM, int W, int NWAVES>
-__device__ __forceinline__ unsigned lane_offset(int ld, int wave, int lane, int i) {
+__device__ __forceinline__ unsigned lane_offset(int ld, int wave, int lane, int i, int valid) {
+  // `valid` (<= W, a multiple of 8): operand rows (columns if k-major) of this tile that exist; the LDS image rows past
+  // them are filled from the last existing one (a ragged last n-tile: their products are never stored)
   constexpr int CNT = (W / 8) / NWAVES;
   const int slab = wave * CNT + i;
   if (!KM) {
     const int row = slab * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ swz_row(row);
-    return (unsigned)(row * ld + chunk * 8) * 2u;
+    return (unsigned)(min(row, valid - 1) * ld + chunk * 8) * 2u;
   } else {
     constexpr int LPR = W / 8, RPS = 64 / LPR;  // lanes per k-row, k-rows per 1-KiB slab
     const int krow = slab * RPS + lane / LPR;
     const int chunk = (lane % LPR) ^ swz_krow(krow);
-    return (unsigned)(krow * ld + chunk * 8) * 2u;
+    return (unsigned)(krow * ld + min(chunk, valid / 8 - 1) * 8) * 2u;
   }
 }
 
@@ -126,7 +131,7 @@ __device__ __forceinline__ void dma2_perlane(const void* p0, const void* p1, uns
 
 template <bool KM, int W, int NWAVES>
 __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, int group, int skip,
-                                           char* lds_tile, int wave, int lane) {
+                                           char* lds_tile, int wave, int lane, int valid = W) {
   constexpr int CNT = (W / 8) / NWAVES;
   static_assert(CNT % 2 == 0, "slabs are issued in pairs");
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(lds_tile) + (unsigned)(wave * CNT) * 1024u;
@@ -149,7 +154,7 @@ __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, in
   const char* ubase = (const char*)org + (size_t)k0 * (KM ? (size_t)ld : (size_t)1) * 2;   // wave-uniform
 #pragma unroll
   for (int i = 0; i < CNT; i += 2)
-    dma2_uniform(ubase, lane_offset<KM, W, NWAVES>(ld, wave, lane, i), lane_offset<KM, W, NWAVES>(ld, wave, lane, i + 1),
+    dma2_uniform(ubase, lane_offset<KM, W, NWAVES>(ld, wave, lane, i, valid), lane_offset<KM, W, NWAVES>(ld, wave, lane, i + 1, valid),
                  lds0 + i * 1024u);
 }
 
@@ -464,7 +469,7 @@ void gemm_kernel(const GemmArgs g) {
     if (g.K < 0)
 #endif
     stage_tile<B_KM, BN, NWAVES>(c.ref.b, g.ldb, (c.ref.kt0 + c.t) * BK, g.b_group, g.b_skip,
-                                 smem + B_RING + b_slot * B_TILE_BYTES, wave, lane);
+                                 smem + B_RING + b_slot * B_TILE_BYTES, wave, lane, min(BN, g.N - c.ref.n0));
     b_slot ^= 1;
   };
   auto issue_a = [&]() {
@@ -533,7 +538,7 @@ void gemm_kernel(const GemmArgs g) {
         ca_slot = ca_slot + 1 == NA ? 0 : ca_slot + 1;
         cb_slot ^= 1;
         produce();                     // B of stage t+1, A of stage t+2
-        if (t == ct.nk - 1) load_cols<KIND>(ep, lane, nw, noff, bias, cs);   // under the last K-step
+        if (t == ct.nk - 1 && nw < g.N) load_cols<KIND>(ep, lane, nw, noff, bias, cs);   // under the last K-step
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           bf16x8 af[MI], bfr[NI];
@@ -552,11 +557,13 @@ void gemm_kernel(const GemmArgs g) {
         }
       }
       if (wm == 0) bar();              // pairs with the lagging group's last barrier: both groups run the epilogue
-      settle_cols<KIND>(bias, cs);     // together (one after the other would double its MFMA-idle time)
-      const size_t ob = (size_t)ct.bz * ep.out_batch_stride;
-      const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
-      if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
-      else epilogue_direct<KIND, MI, false>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+      if (nw < g.N) {                  // (a wave whose 64 columns lie past a ragged N has nothing to store)
+        settle_cols<KIND>(bias, cs);   // together (one after the other would double its MFMA-idle time)
+        const size_t ob = (size_t)ct.bz * ep.out_batch_stride;
+        const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
+        if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+        else epilogue_direct<KIND, MI, false>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+      }
     }
     return;
   }
@@ -724,12 +731,15 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   const bool light_epi = ep->kind == DEVIT_EPI_STORE_BF16 || ep->kind == DEVIT_EPI_STORE_F32;
   const bool gelu_epi = ep->kind == DEVIT_EPI_GELU_BF16 || ep->kind == DEVIT_EPI_DGELU_BF16;
   int cfg = 1;
-  if (M % 256 == 0 && N % 256 == 0 && (K >= 1536 || (K >= 768 && light_epi) || gelu_epi) && variant != 3) cfg = 3;
+  // N = 256 k + 128 (student qkv: 1152) runs the 256-wide tile with a half-empty last n-tile: its B rows past N are
+  // filled from row N-1 and the waves that own them skip the epilogue (variant 0, bf16 / f32 store only)
+  const bool ragged_ok = variant == 0 && light_epi && N % 256 == 128 && N >= 1024;
+  if (M % 256 == 0 && (N % 256 == 0 || ragged_ok) && (K >= 1536 || (K >= DEVIT_RAGGED_MIN_K && light_epi) || gelu_epi) && variant != 3) cfg = 3;
   static const int exact = getenv("DEVIT_GEMM_FORCE") ? atoi(getenv("DEVIT_GEMM_FORCE")) : 0;   // tools/gpu_tiles.sh
-  if (exact == 1 || (exact == 3 && M % 256 == 0 && N % 256 == 0 && variant != 3)) cfg = exact;
+  if (exact == 1 || (exact == 3 && M % 256 == 0 && (N % 256 == 0 || ragged_ok) && variant != 3)) cfg = exact;
   const int bm = cfg == 1 ? 128 : 256, bn = bm;
   g.tiles_m = M / bm;
-  g.tiles_n = N / bn;
+  g.tiles_n = (N + bn - 1) / bn;
   {
     // Tile order inside an XCD: n-tile fastest inside chunks of gn n-tiles, so that the W workgroups an XCD runs at
     // the same time cover about W / gn m-tiles x gn n-tiles and share their operand panels through the XCD's L2 while

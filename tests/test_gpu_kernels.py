@@ -58,6 +58,8 @@ def test_gemm_nt_store(dev, M, N, K):
     (4096, 768, 1536, 2, 3900),      # 256x256 residual epilogue with padding rows in the last m-tile
     (9088, 384, 1536, 6, 9000),      # 71 x 3 = 213 tiles (not a multiple of 8), fp32 store, ragged M
     (6400, 1536, 384, 1, 0),         # GELU + pre-activation, many tiles per workgroup
+    (8192, 1152, 768, 0, 0),         # 256x256 tiles with a ragged last n-tile (N = 4.5 x 256): clamped B rows, skipped waves
+    (2560, 1152, 768, 6, 2500),      # the same, fp32 store, ragged M as well
 ])
 def test_gemm_persistent_schedule(dev, M, N, K, kind, mv):
     """Every output tile of a launch whose workgroups each walk SEVERAL tiles through one continuous LDS ring (cross-tile
