@@ -656,7 +656,11 @@ void gemm_kernel(const GemmArgs g) {
         const int mw = ct.m0 + wm * WM + pass * 64;
         for (int row = 0; row < 64; ++row) {
           const float v = cw[row * 64 + lane];
+#if defined(DEVIT_GEMM_NOATOMIC)  // ablation build: the split-K epilogue without its atomics
+          if (mw + row < m_lim && v == 1.2345e30f) out[(size_t)(mw + row) * ep.ldc + nw + lane] = v;
+#else
           if (mw + row < m_lim) unsafeAtomicAdd(out + (size_t)(mw + row) * ep.ldc + nw + lane, v);
+#endif
         }
       };
       do_pass(std::integral_constant<int, 0>());
