@@ -350,3 +350,33 @@ def test_nondistilled_devit_vs_oracle(dev):
         g_ref = st_g[name].grad
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
         assert rel(p.grad, g_ref.numpy()) < 8e-2, (name, rel(p.grad, g_ref.numpy()))
+
+
+# ------------------------------------------------------------------------------------------ batch-size edges
+def test_batch_invariance_and_ragged_batches(models, dev):
+    """Ragged inputs: batch sizes that fill no tile (1, 3, 19 images = 198 / 594 / 3762 token rows), changing from call
+    to call (workspaces re-sized), train-mode steps in between.  No forward kernel mixes rows of different images, so
+    image i of a batch must give the bits of the same image run alone; bs-1 also goes against the CPU oracle."""
+    s, t, st_s, _ = models
+    img = torch.from_numpy(det_array("ragged", (19, 3, 224, 224), std=0.7)).to(dev)
+    s.eval()
+    with torch.no_grad():
+        full_s, full_t = s(img), t(img)
+        for lo, hi in ((0, 1), (7, 10), (18, 19), (0, 19)):
+            assert torch.equal(s(img[lo:hi]), full_s[lo:hi]), (lo, hi)
+            assert torch.equal(t(img[lo:hi]), full_t[lo:hi]), (lo, hi)
+        ref = O.forward(st_s, GS, img[:1].cpu(), training=False)["output"]
+    assert rel(full_s[:1], ref.numpy()) < 3e-2
+    # a bs-3 training step (forward + backward) between two eval calls leaves the eval result untouched
+    s.train()
+    out = s(img[:3], output_qkv=True)
+    logits = out["output"]
+    loss = sum(o.float().square().mean() for o in (logits if isinstance(logits, tuple) else (logits,)))
+    loss.backward()
+    grads = [p.grad for p in s.parameters() if p.grad is not None]
+    assert grads and all(bool(torch.isfinite(g).all()) for g in grads)
+    s.zero_grad(set_to_none=True)
+    s.eval()
+    with torch.no_grad():
+        assert torch.equal(s(img), full_s)
+    s.train()
