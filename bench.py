@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--teacher-lookahead", type=int, default=1,
                     help="1: teacher forward of batch k+1 runs beside the student step of batch k (default); 0: inside the step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--host-input", action="store_true",
+                    help="PCIe-inclusive variant (DESIGN.md section 6, never the headline value): every step's batch starts "
+                         "in pinned host memory and crosses to the GPU through the training loop's prefetcher")
     return ap.parse_args()
 
 
@@ -140,13 +143,28 @@ def main():
     if look is not None:
         look.submit(img)
 
+    feed = None
+    if args.host_input:
+        class _Repeat:                       # a loader that hands out the same pinned host batch
+            def __init__(self, batch, n): self.batch, self.n = batch, n
+            def __len__(self): return self.n
+            def __iter__(self): return (self.batch for _ in range(self.n))
+        host = (img.cpu().pin_memory(), soft.cpu().pin_memory())
+        if look is not None:
+            look.take(img)
+        feed = iter(engine._PreparedBatches(_Repeat(host, args.warmup + args.steps), dev, None, look))
+
     def step():
         opt.zero_grad()
         t_out = None
-        if look is not None:
-            t_out = look.take(img)
-            look.submit(img)
-        out = engine.distill_forward(student, teacher, img, soft, gama=(0.2, 0.1, 0.3), criterion=criterion,
+        if feed is not None:
+            x, y, t_out = next(feed)
+        else:
+            x, y = img, soft
+            if look is not None:
+                t_out = look.take(img)
+                look.submit(img)
+        out = engine.distill_forward(student, teacher, x, y, gama=(0.2, 0.1, 0.3), criterion=criterion,
                                      teacher_outputs=t_out)
         out["loss"].backward()
         reducer.finish()
@@ -178,9 +196,12 @@ def main():
 
     # ---- dominant-kernel roofline: one extra instrumented step, events on the launch stream ------------------
     os.environ["DEVIT_TEACHER_STREAM"] = "0"      # serialise the two forwards so that event brackets time ONE kernel
-    if look is not None:
+    if feed is not None:
+        assert next(feed, None) is None       # the prefetcher is drained (its last batch submits no look-ahead)
+        feed = None
+    elif look is not None:
         look.take(img)
-        look = None
+    look = None
     step()
     torch.cuda.synchronize()
     ops.PROFILE = []
@@ -215,7 +236,7 @@ def main():
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic, pinned host batches through PCIe every step" if args.host_input else "synthetic",
             "config": {"workload": f"distill_sub step dedeit<-deit_base_distilled_patch16_224, num_division=4 "
                                    f"(C={C}), bs={B}/GPU, 224x224, hard distillation, drop_path 0.1, AdamW+EMA",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(loss_value, 5)},

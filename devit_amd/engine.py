@@ -123,14 +123,32 @@ class _PreparedBatches:
 
     def __init__(self, loader, device, mixup_fn, look):
         self.loader, self.device, self.mixup_fn, self.look = loader, device, mixup_fn, look
+        self._h2d = None
 
     def __len__(self):
         return len(self.loader)
 
+    def _to_device(self, samples, targets):
+        """Host batches cross PCIe on a copy stream of their own (154 MB per bs-256 batch, ~3 ms): _prep runs one
+        batch ahead of the step that consumes it, and the host enqueues ahead of the GPU, so the copy lands under the
+        previous step's kernels instead of in front of this one's (pinned source memory assumed for that)."""
+        dev = torch.device(self.device)
+        if dev.type != "cuda" or (samples.device.type != "cpu" and targets.device.type != "cpu"):
+            return samples.to(dev, non_blocking=True), targets.to(dev, non_blocking=True)
+        if self._h2d is None:
+            self._h2d = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self._h2d):
+            samples = samples.to(dev, non_blocking=True)
+            targets = targets.to(dev, non_blocking=True)
+        main.wait_stream(self._h2d)
+        for t in (samples, targets):
+            t.record_stream(main)
+        return samples, targets
+
     def _prep(self, batch):
         samples, targets = batch
-        samples = samples.to(self.device, non_blocking=True)
-        targets = targets.to(self.device, non_blocking=True)
+        samples, targets = self._to_device(samples, targets)
         if self.mixup_fn is not None:
             samples, targets = self.mixup_fn(samples, targets)
         return samples, targets
