@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--teacher-lookahead", type=int, default=1,
                     help="1: teacher forward of batch k+1 runs beside the student step of batch k (default); 0: inside the step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--classes", type=int, default=0, help="override the class count (default 25 at N=1, 250 at N>1)")
     ap.add_argument("--host-input", action="store_true",
                     help="PCIe-inclusive variant (DESIGN.md section 6, never the headline value): every step's batch starts "
                          "in pinned host memory and crosses to the GPU through the training loop's prefetcher")
@@ -116,7 +117,7 @@ def main():
     from devit_amd import ddp, engine, losses, ops, optim
 
     B = args.batch_size
-    C = 25 if world == 1 else 250           # BASELINE configs[2] (CIFAR-100/4) at N=1, configs[3] (ImageNet/4) at N>1
+    C = args.classes or (25 if world == 1 else 250)          # BASELINE configs[2] (CIFAR-100/4) at N=1, configs[3] (ImageNet/4) at N>1
     torch.manual_seed(0)
     student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None).to(dev).train()
     torch.manual_seed(1)

@@ -380,3 +380,32 @@ def test_batch_invariance_and_ragged_batches(models, dev):
     with torch.no_grad():
         assert torch.equal(s(img), full_s)
     s.train()
+
+
+# ------------------------------------------------------------------------------------------ class counts
+@pytest.mark.parametrize("classes", [10, 250, 1000])
+def test_step_other_class_counts(dev, classes):
+    """BASELINE configs[3] (ImageNet/4: 250 classes, what bench.py runs at N > 1) and the full 1000-class heads: the
+    head GEMMs and the classification-loss kernel at widths other than the fixtures' 25.  bs-3 DEKD step vs the oracle."""
+    import devit_amd
+    from devit_amd import engine
+    st_s, st_t = O.make_state(GS, classes, "S"), O.make_state(GT, classes, "T")
+    s = devit_amd.create_model("dedeit", num_classes=classes, drop_path_rate=0.0, drop_block_rate=None)
+    t = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=classes)
+    s.load_state_dict(st_s)
+    t.load_state_dict(st_t)
+    s, t = s.to(dev).train(), t.to(dev).eval()
+    img = torch.from_numpy(det_array("classes", (3, 3, 224, 224), std=0.7))
+    soft = torch.softmax(torch.from_numpy(det_array("classes_soft", (3, classes), std=2.0)), 1)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in st_s.items()}
+    ref = O.distill_step(leaf, GS, st_t, GT, img, soft)
+    ref["loss"].backward()
+    out = engine.distill_forward(s, t, img.to(dev), soft.to(dev), gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0)
+    out["loss"].backward()
+    for k in ("loss", "cls_loss", "q_loss", "k_loss", "v_loss"):
+        assert abs(float(out[k].detach()) - float(ref[k].detach())) < 2e-2 * abs(float(ref[k].detach())) + 1e-6, k
+    assert rel(out["logits"][0], ref["student"]["output"][0].detach().numpy()) < 3e-2
+    assert rel(out["teacher_logits"], ref["teacher"]["output"].numpy()) < 3e-2
+    got = dict(s.named_parameters())
+    for k in ("head.weight", "head_dist.weight", "head.bias", "blocks.11.mlp.fc2.weight", "blocks.0.attn.qkv.weight"):
+        assert rel(got[k].grad, leaf[k].grad.numpy()) < 6e-2, k
