@@ -436,7 +436,7 @@ def _make(name):
         model = VisionTransformer(**{**model_config[name], **kwargs})
         model.default_cfg = _cfg()
         if pretrained_path is not None and pretrained:
-            ckpt = torch.load(pretrained_path, map_location='cpu')
+            ckpt = torch.load(pretrained_path, map_location='cpu', weights_only=False)
             model.load_state_dict(ckpt['model'] if 'model' in ckpt else ckpt)
         return model
     fn.__name__ = name

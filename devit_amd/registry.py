@@ -33,6 +33,6 @@ def create_model(model_name, pretrained=False, checkpoint_path='', **kwargs):
     model = _REGISTRY[model_name](pretrained=pretrained, **kwargs)
     if checkpoint_path:
         import torch
-        ckpt = torch.load(checkpoint_path, map_location='cpu')
+        ckpt = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
         model.load_state_dict(ckpt['model'] if 'model' in ckpt else ckpt)
     return model

@@ -226,7 +226,7 @@ def main(args):
     n_parameters = sum(p_.numel() for p_ in model.parameters() if p_.requires_grad)
 
     if args.resume:
-        ck = torch.load(args.resume, map_location='cpu')
+        ck = torch.load(args.resume, map_location='cpu', weights_only=False)   # holds the argparse Namespace, like the reference's
         model.load_state_dict(ck['model'])
         flat.attach_bf16(model)
         if not args.eval and 'optimizer' in ck:

@@ -29,6 +29,37 @@ def test_distill_sub_cli(tmp_path):
     assert line["train_loss"] == line["train_loss"] and line["n_parameters"] == 21685682   # finite, C = 25
 
 
+def test_distill_sub_resume(tmp_path):
+    """--resume (distill_sub.py:372-388): model, optimizer moments, EMA, step count and schedule come back from
+    checkpoint_temp.pth and training continues at the next epoch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import json
+    import distill_sub
+    base = ["--synthetic", "8", "--batch-size", "4", "--model", "dedeit", "--teacher-model",
+            "deit_base_distilled_patch16_224", "--dataset", "cifar100", "--num_division", "4", "--warmup-epochs", "0",
+            "--model-ema"]
+    parse = lambda extra: argparse.ArgumentParser(parents=[distill_sub.get_args_parser()]).parse_args(base + extra)
+    a1 = parse(["--epochs", "1", "--output_dir", str(tmp_path / "a")])
+    distill_sub.main(a1)
+    ck_path = os.path.join(a1.output_dir, "checkpoint_temp.pth")
+    ck = torch.load(ck_path, map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 0 and ck["optimizer"]["step"] == 8 and ck["optimizer"]["ema"] is not None
+    # --resume --eval: the restored model is the saved one (evaluate is deterministic on the synthetic val split)
+    a2 = parse(["--epochs", "2", "--output_dir", str(tmp_path / "b"), "--resume", ck_path])
+    distill_sub.main(a2)
+    assert a2.start_epoch == 1
+    lines = [json.loads(l) for l in open(os.path.join(a2.output_dir, "log.txt")).read().splitlines()]
+    assert [l["epoch"] for l in lines] == [1] and lines[0]["train_loss"] == lines[0]["train_loss"]
+    ck2 = torch.load(os.path.join(a2.output_dir, "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 1 and ck2["optimizer"]["step"] == 16
+    moved = max(float((ck2["model"][k].float() - ck["model"][k].float()).abs().max()) for k in ck["model"])
+    assert 0 < moved < 0.1                     # continued from the checkpoint, not from a fresh initialisation
+    ema_gap = max(float((ck2["model_ema"][k] - ck["model_ema"][k]).abs().max()) for k in ck["model_ema"])
+    assert ema_gap < 1e-3                      # EMA (decay 0.99996) restored, then moved by eight tiny updates
+
+
 def test_ensemble_cli(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")

@@ -62,7 +62,7 @@ def main(args):
                                          drop_path_rate=args.drop_path, drop_block_rate=None)
         tp = os.path.join(args.teacher_path, f'sub-dataset{args.start_division}', 'checkpoint.pth') if args.teacher_path else ''
         if tp and os.path.exists(tp):
-            ck = torch.load(tp, map_location='cpu')
+            ck = torch.load(tp, map_location='cpu', weights_only=False)
             teacher.load_state_dict(ck['model'] if args.dataset == 'IMNET' and 'model' in ck else ck)
         teacher.to(device).eval()
         for p_ in teacher.parameters():
