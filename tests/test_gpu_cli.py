@@ -60,6 +60,35 @@ def test_distill_sub_resume(tmp_path):
     assert ema_gap < 1e-3                      # EMA (decay 0.99996) restored, then moved by eight tiny updates
 
 
+def test_distill_sub_finetune_and_eval(tmp_path, capsys):
+    """--model-path/--finetune (distill_sub.py:205-226: a 1000-class checkpoint, then reset_classifier to the
+    sub-dataset's classes) and --eval --resume (:390-393)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import devit_amd
+    import distill_sub
+    torch.manual_seed(5)
+    pre = devit_amd.create_model("dedeit", num_classes=1000)
+    torch.save({"model": pre.state_dict()}, tmp_path / "pre.pth")
+    base = ["--synthetic", "2", "--batch-size", "4", "--model", "dedeit", "--teacher-model",
+            "deit_base_distilled_patch16_224", "--dataset", "cifar100", "--num_division", "4", "--warmup-epochs", "0",
+            "--epochs", "1"]
+    parse = lambda extra: argparse.ArgumentParser(parents=[distill_sub.get_args_parser()]).parse_args(base + extra)
+    a = parse(["--output_dir", str(tmp_path / "ft"), "--model-path", str(tmp_path / "pre.pth"), "--finetune"])
+    distill_sub.main(a)
+    ck = torch.load(os.path.join(a.output_dir, "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
+    assert ck["model"]["head.weight"].shape == (25, 384) and ck["model"]["head_dist.weight"].shape == (25, 384)
+    # two steps at lr ~4e-6 leave the backbone next to the pretrained weights (it was loaded, not re-initialised)
+    k = "blocks.5.mlp.fc1.weight"
+    assert float((ck["model"][k] - pre.state_dict()[k]).abs().max()) < 1e-3
+    capsys.readouterr()
+    e = parse(["--output_dir", str(tmp_path / "ev"), "--resume", os.path.join(a.output_dir, "checkpoint_temp.pth"), "--eval"])
+    distill_sub.main(e)
+    printed = capsys.readouterr().out
+    assert "acc1" in printed and not os.path.exists(os.path.join(e.output_dir, "log.txt"))
+
+
 def test_ensemble_cli(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
