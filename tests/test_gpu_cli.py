@@ -152,3 +152,47 @@ def test_distillation_loss_equals_distill_loss():
                 ref = 0.5 * b + 0.5 * torch.nn.functional.kl_div(torch.log_softmax(lk / 2, 1), torch.log_softmax(lt / 2, 1),
                                                                  reduction="sum", log_target=True) * 4 / lk.numel()
             assert abs(float(got) - float(ref)) < 1e-5 * abs(float(ref)), (kind, float(got), float(ref))
+
+
+def test_ensemble_cli_checkpoints_gates_shrink(tmp_path, capsys):
+    """ensemble.py --eval from files: four sub-model checkpoints (`{model-path}/sub-dataset{i}/checkpoint.pth`), the
+    teacher checkpoint, gates persisted beside them, and the physically shrunk model giving the masked model's scores."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import re
+    import devit_amd
+    import ensemble
+    from devit_amd import shrink
+    from devit_amd.ensemble_models import MultiViT
+    torch.manual_seed(11)
+    for i in range(4):
+        os.makedirs(tmp_path / "subs" / f"sub-dataset{i}")
+        torch.save(devit_amd.create_model("dedeit", num_classes=25).state_dict(),
+                   tmp_path / "subs" / f"sub-dataset{i}" / "checkpoint.pth")
+    torch.save(devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=100).state_dict(), tmp_path / "teacher.pth")
+    multi = MultiViT(model="dedeit", num_div=4, num_classes_list=[25] * 4)
+    g = torch.Generator().manual_seed(3)
+    pol = []
+    for _ in range(4 * 12):                      # per block: 4 of 6 heads, 1024 of 1536 neurons stay
+        h, n = torch.zeros(6), torch.zeros(1536)
+        h[torch.randperm(6, generator=g)[:4]] = 1
+        n[torch.randperm(1536, generator=g)[:1024]] = 1
+        pol.append((h, n))
+    shrink.load_policy(multi, pol)
+    shrink.save_gates(multi, tmp_path / "gates.pt")
+    base = ["--synthetic", "8", "--batch-size", "4", "--model", "dedeit", "--teacher-model", "deit_base_distilled_patch16_224",
+            "--model-path", str(tmp_path / "subs"), "--teacher-path", str(tmp_path / "teacher.pth"), "--eval",
+            "--gates", str(tmp_path / "gates.pt"), "--output_dir", str(tmp_path)]
+    parse = lambda extra: argparse.ArgumentParser(parents=[ensemble.get_args_parser()], conflict_handler='resolve').parse_args(base + extra)
+    scores = []
+    for extra in ([], ["--physical-shrink"]):
+        capsys.readouterr()
+        ensemble.main(parse(extra))
+        out = capsys.readouterr().out
+        m = re.search(r"\{'loss': ([0-9.eE+-]+), 'acc1': ([0-9.eE+-]+), 'acc5': ([0-9.eE+-]+)\}", out)
+        assert m, out[-400:]
+        scores.append([float(v) for v in m.groups()])
+        if extra:
+            assert "physically shrunk 48 blocks" in out
+    assert abs(scores[0][0] - scores[1][0]) < 2e-2 * abs(scores[0][0]) and scores[0][1:] == scores[1][1:]
