@@ -15,6 +15,7 @@ Layout conventions
 import ctypes as C
 import math
 
+import os
 import torch
 
 from . import _lib as L
@@ -312,6 +313,9 @@ class EncoderFn(torch.autograd.Function):
                 encs.append(x.clone() if i == len(cfg.blocks) - 1 else x)
         ctx.cfg, ctx.saved, ctx.need_grad = cfg, saved, need_grad
         ctx.counts = (len(qkvs), len(atts), len(encs))
+        # outputs nobody differentiates (11 of the 12 qkv tensors in the DEKD step) arrive as None in backward, not as
+        # zero tensors: a materialised one is a 117 MB fill plus a 117 MB read in the attention backward, per block
+        ctx.set_materialize_grads(False)
         return (x,) + tuple(qkvs) + tuple(atts) + tuple(encs)
 
     @staticmethod
@@ -433,6 +437,7 @@ class HeadsFn(torch.autograd.Function):
         ctx.save = (x, tok, mean, rstd)
         ctx.params = (norm_w, norm_b, head_w, head_b, headd_w, headd_b)
         ctx.meta = (B, T, D, ntok, eps, grad_ready)
+        ctx.set_materialize_grads(False)
         return tuple(outs)
 
     @staticmethod

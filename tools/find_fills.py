@@ -1,8 +1,10 @@
-"""Diagnostic: where do the aten fill kernels of a bench step come from?"""
-import os, sys, torch, traceback, collections
+#!/usr/bin/env python3
+"""Which torch (non-library) device work does one DEKD step still contain?  aten ops by device time, with shapes."""
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import devit_amd
 from devit_amd import ddp, engine, losses, optim
+from torch.profiler import profile, ProfilerActivity
 dev = torch.device("cuda"); B, C = 256, 25
 student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None).to(dev).train()
 teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
@@ -16,24 +18,16 @@ def step():
     opt.zero_grad(); t = look.take(img); look.submit(img)
     out = engine.distill_forward(student, teacher, img, soft, criterion=crit, teacher_outputs=t)
     out["loss"].backward(); reducer.finish(); opt.step()
-for _ in range(2): step()
+for _ in range(3): step()
 torch.cuda.synchronize()
-cnt = collections.Counter()
-orig_zero, orig_fill = torch.Tensor.zero_, torch.Tensor.fill_
-def wrap(name, fn):
-    def f(self, *a, **k):
-        st = [l for l in traceback.format_stack(limit=8) if "devit_amd" in l or "bench" in l]
-        cnt[(name, str(self.dtype), tuple(self.shape), st[-1].strip().split("\n")[0] if st else "?")] += 1
-        return fn(self, *a, **k)
-    return f
-torch.Tensor.zero_ = wrap("zero_", orig_zero); torch.Tensor.fill_ = wrap("fill_", orig_fill)
-for n in ("zeros", "zeros_like", "full", "ones"):
-    o = getattr(torch, n)
-    def mk(o=o, n=n):
-        def f(*a, **k):
-            st = [l for l in traceback.format_stack(limit=8) if "devit_amd" in l]
-            r = o(*a, **k); cnt[(n, str(r.dtype), tuple(r.shape), st[-1].strip().split("\n")[0] if st else "?")] += 1; return r
-        return f
-    setattr(torch, n, mk())
-step(); torch.cuda.synchronize()
-for k, v in sorted(cnt.items(), key=lambda kv: -kv[1]): print(v, k)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    step(); torch.cuda.synchronize()
+import collections
+agg = collections.Counter(); tm = collections.Counter()
+for ev in prof.events():
+    if ev.name.startswith("aten::") and ev.device_time_total > 0:
+        st = [s for s in ev.stack if "devit_amd" in s or "bench" in s or "tools/" in s][:2]
+        key = (ev.name, str(ev.input_shapes)[:60], " <- ".join(s.split("/")[-1] for s in st))
+        agg[key] += 1; tm[key] += ev.device_time_total
+for k, v in sorted(tm.items(), key=lambda kv: -kv[1])[:45]:
+    print(f"{v:9.1f} us  x{agg[k]:3d}  {k}")
