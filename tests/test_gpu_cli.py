@@ -151,6 +151,7 @@ def test_distillation_loss_equals_distill_loss():
             else:
                 ref = 0.5 * b + 0.5 * torch.nn.functional.kl_div(torch.log_softmax(lk / 2, 1), torch.log_softmax(lt / 2, 1),
                                                                  reduction="sum", log_target=True) * 4 / lk.numel()
+            got, ref = got.detach(), ref.detach()
             assert abs(float(got) - float(ref)) < 1e-5 * abs(float(ref)), (kind, float(got), float(ref))
 
 
