@@ -366,6 +366,17 @@ __device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 
 }
 
 // Where one output tile's operands start and which K-steps it covers (all wave-uniform).
+// acc + sum of the eight bf16 values of one MFMA fragment (four v_dot2c_f32_bf16 against packed ones)
+__device__ __forceinline__ float sum8_bf16(bf16x8 v, float acc) {
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  const bf16x2v one = {(__bf16)1.0f, (__bf16)1.0f};
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 4, 5), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 6, 7), one, acc, false);
+  return acc;
+}
+
 struct TileRef {
   const __bf16* a;
   const __bf16* b;
@@ -588,6 +599,13 @@ void gemm_kernel(const GemmArgs g) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Split-K weight gradient: the row sums of A (= dY^T, i.e. the bias gradient) come from the fragments the MFMAs
+    // read anyway -- one v_dot2c_f32_bf16 per two elements, on the waves that own the first 64 output columns of the
+    // first n-tile only (every A row is seen exactly once per k-slice there).
+    float rsum[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rsum[i] = 0.f;
+    const bool rowsum_on = KIND == DEVIT_EPI_ATOMIC_F32 && g.ep.aux != nullptr && ct.n0 == 0 && wn == 0;
 
     auto kstep = [&]() {
       const char* cur_a = smem + ca_slot * A_TILE_BYTES;
@@ -609,6 +627,12 @@ void gemm_kernel(const GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < NI; ++j)
             acc[i][j] = DIRECT ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+        if constexpr (KIND == DEVIT_EPI_ATOMIC_F32) {
+          if (rowsum_on) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) rsum[i] = sum8_bf16(af[i], rsum[i]);
+          }
+        }
       }
     };
     const devit_epilogue& ep = g.ep;
@@ -665,6 +689,18 @@ void gemm_kernel(const GemmArgs g) {
       };
       do_pass(std::integral_constant<int, 0>());
       if constexpr (MI > 4) do_pass(std::integral_constant<int, 1>());
+      if (rowsum_on) {
+        // lane l holds the partial sum of row (l & 15) over k = 8 (l >> 4) + 0..7 of every K-step: fold the four k groups
+        float* rs_out = (float*)ep.aux;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          float v = rsum[i];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          const int row = ct.m0 + wm * WM + i * 16 + lane;
+          if (lane < 16 && row < m_lim) unsafeAtomicAdd(rs_out + row, v);
+        }
+      }
       if (pb.tile < last) {          // restart the stream on the next tile
         __syncthreads();             // every wave's staging reads done before the DMA overwrites them
         pb.ref = decode_tile<BM, BN, A_KM, B_KM>(g, pb.tile);
@@ -711,6 +747,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
                 DEVIT_ERR_ARG,
                 "PATCH: pos / tokens");
   if (ep->kind == DEVIT_EPI_DGELU_BF16) DEVIT_CHECK(ep->aux_in != nullptr, DEVIT_ERR_ARG, "DGELU: aux_in");
+  if (ep->kind == DEVIT_EPI_ATOMIC_F32 && ep->aux)
+    DEVIT_CHECK(batch == 1, DEVIT_ERR_ARG, "ATOMIC: the fused row sums of A (aux) need batch == 1");
   DEVIT_CHECK(ep->exact_gelu == 0, DEVIT_ERR_ARG, "devit_gemm_bf16: exact_gelu=1 (erff) is not built; the fused GELU uses a "
               "1.5e-7-accurate erf");
 

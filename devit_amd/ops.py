@@ -111,13 +111,12 @@ def linear_dgrad(dy, w, M, *, out, kind=L.EPI_STORE_BF16, **kw):
 
 
 def linear_wgrad(dy, x, w_grad, b_grad, M, **kw):
-    """w_grad[N, K] += dy[Mp, N]^T @ x[Mp, K];  b_grad[N] += colsum(dy).  Pad rows of dy are zero."""
+    """w_grad[N, K] += dy[Mp, N]^T @ x[Mp, K];  b_grad[N] += colsum(dy), one launch.  Pad rows of dy are zero."""
     N, K = w_grad.shape
     mp = pad_rows(M)
+    # b_grad: the row sums of dy^T come out of the same launch (fragments the MFMAs read anyway; no second pass over dy)
     gemm(dy, dy.stride(0), 1, x, x.stride(0), 1, N, K, mp, kind=L.EPI_ATOMIC_F32, out=w_grad, ldc=K,
-         split_k=split_k_for(N, K, mp // 64), **kw)
-    if b_grad is not None:
-        colsum(dy, M, N, b_grad, accumulate=True)
+         split_k=split_k_for(N, K, mp // 64), aux=b_grad, **kw)
 
 
 def colsum(y, M, N, out, accumulate, row_group=0, row_skip=0):

@@ -67,7 +67,8 @@ typedef enum {
                             /*   (forward_features :258-264; cls/dist rows written by            */
                             /*   devit_embed_tokens)                                             */
   DEVIT_EPI_DGELU_BF16 = 4, /* out_bf16 = acc * colscale * gelu'(aux_in_bf16)  (fc2 dgrad -> dfc1) */
-  DEVIT_EPI_ATOMIC_F32 = 5, /* out_f32 += acc   (atomicAdd; wgrad with split-K)                  */
+  DEVIT_EPI_ATOMIC_F32 = 5, /* out_f32 += acc   (atomicAdd; wgrad with split-K); aux_f32[m] += sum_k A[m][k]       */
+                            /*   when aux != NULL (the bias gradient of the same Linear: A = dY^T), batch == 1   */
   DEVIT_EPI_STORE_F32 = 6   /* out_f32 = acc + bias                                             */
 } devit_epilogue_kind;
 
@@ -77,7 +78,8 @@ typedef struct {
   int ldc;
   const float* bias;       /* [N] or NULL */
   const float* colscale;   /* [N] gate (GELU / DGELU) or NULL (= 1) */
-  void* aux;               /* GELU: pre-activation out (bf16, ld = ldc) or NULL; RESIDUAL: bf16 copy or NULL */
+  void* aux;               /* GELU: pre-activation out (bf16, ld = ldc) or NULL; RESIDUAL: bf16 copy or NULL;
+                              ATOMIC: f32 [M] row sums of A, accumulated, or NULL */
   const void* aux_in;      /* DGELU: saved pre-activation [M][ldc] bf16 */
   const float* res;        /* RESIDUAL: [M][ldc] f32 input stream (may alias out) */
   const float* rowscale;   /* RESIDUAL: [M / rows_per_scale] per-sample DropPath scale or NULL */

@@ -101,6 +101,28 @@ def test_gemm_wgrad_persistent(dev):
     assert relerr(out, dy.float().t() @ x.float()) < 2e-5
 
 
+@pytest.mark.parametrize("rows,N,K,split", [(16384, 1536, 384, 20), (50688, 1152, 384, 18), (2560, 384, 1536, 3),
+                                            (1024, 128, 128, 1)])
+def test_gemm_wgrad_fused_bias_grad(dev, rows, N, K, split):
+    """aux of the split-K epilogue: b_grad[n] += sum_m dy[m][n] from the same launch (row sums of the A fragments),
+    accumulated onto what the buffer held; integer-valued dy -> the sums are exact in fp32."""
+    from devit_amd import ops, _lib as L
+    g = torch.Generator(device="cpu").manual_seed(rows + N)
+    dy = torch.randint(-3, 4, (rows, N), generator=g).to(BF16).to(dev)
+    x = rnd((rows, K), dev, seed=3, dtype=BF16)
+    out = torch.zeros((N, K), dtype=F32, device=dev)
+    bg = torch.full((N,), 2.0, dtype=F32, device=dev)
+    ops.gemm(dy, N, 1, x, K, 1, N, K, rows, kind=L.EPI_ATOMIC_F32, out=out, ldc=K, split_k=split, aux=bg)
+    assert relerr(out, dy.float().t() @ x.float()) < 2e-5
+    assert torch.equal(bg, dy.float().sum(0) + 2.0)
+    # random (non-integer) data against the fp32 column sums
+    dy = rnd((rows, N), dev, seed=5, dtype=BF16)
+    bg.zero_()
+    out.zero_()
+    ops.gemm(dy, N, 1, x, K, 1, N, K, rows, kind=L.EPI_ATOMIC_F32, out=out, ldc=K, split_k=split, aux=bg)
+    assert relerr(bg, dy.float().sum(0)) < 2e-5
+
+
 def test_gemm_layout_asymmetric(dev):
     """A = I-like selector with an asymmetric B catches swapped row/col maps (cdna guide §3)."""
     from devit_amd import ops, _lib as L

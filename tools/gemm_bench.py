@@ -55,7 +55,11 @@ for tag, D in (("S", 384), ("T", 768)):
         gq = torch.zeros(D, D, device=dev)
         for sk in (28, 56, 113):
             report(f"S proj wgrad split_k={sk:3d} [384,384]", 2.0 * M * D * D, timeit(lambda: ops.gemm(x, D, 1, x, D, 1, D, D, M, kind=L.EPI_ATOMIC_F32, out=gq, ldc=D, split_k=sk)))
+        bgk = torch.zeros(3 * D, device=dev); bg1 = torch.zeros(4 * D, device=dev)
+        report("S fc1 wgrad split_k=14 + bias grad (fused)", 2.0 * M * 4 * D * D, timeit(lambda: ops.gemm(xh, 4 * D, 1, x, D, 1, 4 * D, D, M, kind=L.EPI_ATOMIC_F32, out=gw, ldc=D, split_k=14, aux=bg1)))
+        report("S fc1 bias grad alone (colsum pass)", 2.0 * M * 4 * D * D, timeit(lambda: ops.colsum(xh, M, 4 * D, bg1, accumulate=True)))
         gk = torch.zeros(3 * D, D, device=dev)
+        report("S qkv wgrad split_k=18 + bias grad (fused)", 2.0 * M * 3 * D * D, timeit(lambda: ops.gemm(o3, 3 * D, 1, x, D, 1, 3 * D, D, M, kind=L.EPI_ATOMIC_F32, out=gk, ldc=D, split_k=18, aux=bgk)))
         for sk in (9, 18, 37):
             report(f"S qkv wgrad split_k={sk:3d} [1152,384]", 2.0 * M * 3 * D * D, timeit(lambda: ops.gemm(o3, 3 * D, 1, x, D, 1, 3 * D, D, M, kind=L.EPI_ATOMIC_F32, out=gk, ldc=D, split_k=sk)))
 os.makedirs("gpurun_out", exist_ok=True)
