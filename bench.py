@@ -195,7 +195,20 @@ def main():
     assert loss_value == loss_value, "non-finite loss"
     img_per_s = B * world * args.steps / dt
 
-    # ---- dominant-kernel roofline: one extra instrumented step, events on the launch stream ------------------
+    # ---- dominant-kernel roofline: extra instrumented steps, events on the launch stream ---------------------
+    # (a) as in the timed region: the teacher's launches share the GPU with the student's (two streams), so an event
+    #     bracket there also contains the other model's workgroups -- this is what a rocprofv3 average over the run sees
+    two_stream = None
+    if look is not None and feed is None:
+        ops.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        sel = [(2.0 * M * N * K * batch, e0.elapsed_time(e1) * 1e-3) for t, M, N, K, batch, e0, e1 in recs if t == "A_row/B_row"]
+        fl2, tm2 = sum(f for f, _ in sel), sum(t for _, t in sel)
+        two_stream = {"achieved": round(fl2 / tm2 / 1e12, 2), "avg_launch_us": round(tm2 / len(sel) * 1e6, 2),
+                      "launches_per_step": len(sel)}
+    # (b) one launch at a time (`achieved` below): the kernel's own rate
     os.environ["DEVIT_TEACHER_STREAM"] = "0"      # serialise the two forwards so that event brackets time ONE kernel
     if feed is not None:
         assert next(feed, None) is None       # the prefetcher is drained (its last batch submits no look-ahead)
@@ -225,7 +238,8 @@ def main():
             "step_frac": round(img_per_s / world * GFLOP_PER_IMG_STEP * 1e9 / BF16_DENSE_PEAK, 4),
             "other_templates": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "launches": v[2],
                                     "ms_per_step": round(v[1] * 1e3, 3)} for k, v in by_t.items() if k != dom},
-            "gemm_ms_per_step": round(sum(v[1] for v in by_t.values()) * 1e3, 3)}
+            "gemm_ms_per_step": round(sum(v[1] for v in by_t.values()) * 1e3, 3),
+            "in_two_stream_timed_region": two_stream}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
