@@ -20,7 +20,9 @@ class FlatAdamW:
         self.step_count = 0
         self.param_groups = [{"lr": lr, "params": flat.params}]
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._dyn_host = torch.zeros(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(3)
+        # per-step scalars (lr, bias corrections) travel through pinned memory with an async copy; the host runs ahead of
+        # the GPU, so every step in flight needs its own slot (a ring far deeper than the launch queue)
+        self._dyn_host = torch.zeros((256, 3), dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros((256, 3))
         self._dyn = torch.zeros(3, dtype=torch.float32, device=dev)
         self._ws = torch.empty(4096, dtype=torch.uint8, device=dev)
 
@@ -31,10 +33,11 @@ class FlatAdamW:
         L.require_device(self.flat.flat)
         self.step_count += 1
         b1, b2 = self.betas
-        self._dyn_host[0] = self.param_groups[0]["lr"]
-        self._dyn_host[1] = 1.0 - b1 ** self.step_count
-        self._dyn_host[2] = 1.0 - b2 ** self.step_count
-        self._dyn.copy_(self._dyn_host, non_blocking=True)
+        slot = self._dyn_host[self.step_count % self._dyn_host.shape[0]]
+        slot[0] = self.param_groups[0]["lr"]
+        slot[1] = 1.0 - b1 ** self.step_count
+        slot[2] = 1.0 - b2 ** self.step_count
+        self._dyn.copy_(slot, non_blocking=True)
         f = self.flat
         clip = self.max_norm is not None and self.max_norm > 0
         if clip:
