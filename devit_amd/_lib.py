@@ -67,6 +67,10 @@ SIGNATURES = {
     "devit_im2row_f32": (_I, [_P, _P, _I, _P]),
     "devit_scale_rows_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "devit_colsum_f32": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "devit_comm_unique_id": (_I, [_P]),
+    "devit_comm_init": (_I, [_P, _I, _I, C.POINTER(C.c_void_p)]),
+    "devit_comm_allreduce_f32": (_I, [_P, _P, _Z, _P]),
+    "devit_comm_destroy": (_I, [_P]),
 }
 
 _lib = None

@@ -62,12 +62,53 @@ class FlatParams:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
 
 
+class RcclComm:
+    """The C ABI's own RCCL communicator (devit_comm_*): for hosts that do not route collectives through
+    torch.distributed.  The 128-byte rendezvous id travels over whatever process group is already up (any backend; only
+    its object broadcast is used) or is handed in by the launcher.  `all_reduce` is asynchronous on the given stream."""
+
+    def __init__(self, rank=None, world=None, unique_id=None, group=None):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if unique_id is None:
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                L.call("devit_comm_unique_id", buf)
+            box = [bytes(buf.raw)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            unique_id = box[0]
+        self.rank, self.world = rank, world
+        self._comm = C.c_void_p()
+        L.call("devit_comm_init", C.c_char_p(unique_id), rank, world, C.byref(self._comm))
+
+    def all_reduce(self, flat_f32, stream=None):
+        """In-place SUM over ranks of a contiguous fp32 CUDA tensor, enqueued on `stream` (default: current)."""
+        L = self._L
+        L.require_device(flat_f32)
+        if flat_f32.dtype != torch.float32 or not flat_f32.is_contiguous():
+            raise L.DevitError("RcclComm.all_reduce: contiguous float32 tensor expected")
+        s = stream if stream is not None else torch.cuda.current_stream()
+        L.call("devit_comm_allreduce_f32", self._comm, flat_f32.data_ptr(), flat_f32.numel(), s.cuda_stream)
+
+    def destroy(self):
+        if self._comm:
+            self._L.call("devit_comm_destroy", self._comm)
+            self._comm = self._C.c_void_p()
+
+
 class BucketedGradReducer:
     """All-reduce (mean) of FlatParams.flat_grad in buckets, fired from `grad_ready` callbacks."""
 
-    def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, process_group=None):
-        self.flat, self.group = flat, process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+    def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, process_group=None, comm=None):
+        """comm: an RcclComm -> the buckets go through the C ABI's communicator instead of torch.distributed's."""
+        self.flat, self.group, self.comm = flat, process_group, comm
+        self.world = comm.world if comm is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         # bucket boundaries on parameter boundaries, in flat (= reverse forward) order
         self.buckets, start, last = [], 0, 0
         limit = bucket_bytes // 4
@@ -113,6 +154,9 @@ class BucketedGradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())          # backward kernels of this bucket are enqueued
             self.stream.wait_event(ev)
+            if self.comm is not None:
+                self.comm.all_reduce(view, stream=self.stream)
+                return
             with torch.cuda.stream(self.stream):
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

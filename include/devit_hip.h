@@ -237,6 +237,22 @@ int devit_scale_rows_f32(const float* src, float* dst, const float* rowscale, in
                          void* stream);
 int devit_colsum_f32(const float* y, int M, int N, int ld, float* out, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Gradient exchange of the data-parallel step (distill_sub.py:333: DistributedDataParallel's reducer):
+ * RCCL all-reduce over xGMI, one communicator per process (= per GPU).  RCCL is bound at run time (dlopen; a copy the
+ * process already holds, e.g. PyTorch's, is reused), so the library has no link-time dependency on it.
+ *   devit_comm_unique_id: rank 0 creates the 128-byte rendezvous id and hands it to the other ranks by any host
+ *     channel (the launcher's store, a file, torch.distributed's object broadcast).
+ *   devit_comm_init: collective over all ranks; uses the calling thread's current HIP device.
+ *   devit_comm_allreduce_f32: in-place SUM of buf[count] on `stream` (asynchronous, like every other entry point);
+ *     the caller scales by 1/world (devit_adamw_step's grad_scale) -- one bucket of the flat gradient buffer per call.
+ * ---------------------------------------------------------------------------------------- */
+#define DEVIT_COMM_ID_BYTES 128
+int devit_comm_unique_id(void* id /* [DEVIT_COMM_ID_BYTES] host */);
+int devit_comm_init(const void* id, int rank, int world, void** comm);
+int devit_comm_allreduce_f32(void* comm, float* buf, size_t count, void* stream);
+int devit_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

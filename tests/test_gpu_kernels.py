@@ -415,3 +415,23 @@ def test_adamw_and_sumsq(dev):
     assert abs(float(gsq) - float((g * g).sum())) < 1e-4 * float((g * g).sum())
     assert relerr(p, ref_p.detach()) < 1e-5 and relerr(ema, ema_ref) < 1e-5
     assert torch.equal(p16, p.to(BF16))
+
+
+def test_comm_rccl_single_rank(dev):
+    """devit_comm_*: the C ABI's RCCL binding (dlopen) on one rank -- unique id, communicator, an in-place SUM all-reduce
+    on a side stream (identity at world size 1), destroy.  The multi-rank exchange itself is RCCL's."""
+    from devit_amd import ddp
+    comm = ddp.RcclComm(rank=0, world=1)
+    x = torch.randn(1 << 20, device=dev)
+    y = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce(y, stream=side)
+    comm.all_reduce(y[: 1000], stream=side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    with pytest.raises(Exception):
+        comm.all_reduce(y.double())
+    comm.destroy()
+    comm.destroy()            # idempotent

@@ -4,9 +4,9 @@ set -e
 NAME=$1; EXTRA=$2
 cd "$(dirname "$0")/../devit_amd/csrc"
 mkdir -p build_$NAME ../../tools/_diag
-for f in api gemm layernorm attention elementwise losses sgemm; do
+for f in api gemm layernorm attention elementwise losses sgemm comm; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $EXTRA -c $f.hip -o build_$NAME/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_diag/libdevit_$NAME.so build_$NAME/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_diag/libdevit_$NAME.so build_$NAME/*.o -ldl
 echo built variant $NAME
