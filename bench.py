@@ -218,10 +218,20 @@ def main():
     look = None
     step()
     torch.cuda.synchronize()
-    ops.PROFILE = []
+    ops.PROFILE, ops.PROFILE_HBM = [], []
     step()
     torch.cuda.synchronize()
     recs, ops.PROFILE = ops.PROFILE, None
+    hbm_recs, ops.PROFILE_HBM = ops.PROFILE_HBM, None
+    # the bandwidth-bound kernels of the same serialized step: algorithmic bytes / event time (HBM peak 8 TB/s)
+    hbm = {}
+    for name, nbytes, e0, e1 in hbm_recs:
+        d = hbm.setdefault(name, [0.0, 0.0, 0])
+        d[0] += nbytes
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    hbm = {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "frac_of_8TB/s": round(v[0] / v[1] / 8e12, 3), "launches": v[2],
+               "ms_per_step": round(v[1] * 1e3, 3)} for k, v in hbm.items()}
     by_t = {}
     for tmpl, M, N, K, batch, e0, e1 in recs:
         d = by_t.setdefault(tmpl, [0.0, 0.0, 0])
@@ -239,7 +249,7 @@ def main():
             "other_templates": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "launches": v[2],
                                     "ms_per_step": round(v[1] * 1e3, 3)} for k, v in by_t.items() if k != dom},
             "gemm_ms_per_step": round(sum(v[1] for v in by_t.values()) * 1e3, 3),
-            "in_two_stream_timed_region": two_stream}
+            "in_two_stream_timed_region": two_stream, "hbm_bound_kernels": hbm}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

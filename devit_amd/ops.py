@@ -88,6 +88,22 @@ def _profiled_gemm(kw):
         PROFILE = rec
 
 
+# Second instrument of bench.py: the bandwidth-bound kernels.  When PROFILE_HBM is a list, each LayerNorm / attention launch
+# is bracketed by events on its stream and recorded as (name, algorithmic bytes, start_event, end_event).
+PROFILE_HBM = None
+
+
+def _bracketed(name, nbytes, fn):
+    rec = PROFILE_HBM
+    if rec is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    rec.append((name, nbytes, e0, e1))
+
+
 def split_k_for(out_rows, out_cols, ksteps):
     """Split-K factor of a weight-gradient GEMM: exactly one round of resident workgroups (128x128 tiles, two per
     CU).  More slices only add fp32-atomic traffic (64 KB per workgroup at ~1.3 TB/s chip-wide): measured 640 vs 521
@@ -128,17 +144,24 @@ def colsum(y, M, N, out, accumulate, row_group=0, row_skip=0):
 
 def layernorm_fwd(x2d, rows, D, gamma, beta, eps, *, y_bf16=None, y_f32=None, mean=None, rstd=None, in_group=0,
                   in_stride=0):
-    call("devit_layernorm_fwd", ptr(x2d), rows, D, in_group, in_stride, ptr(gamma), ptr(beta), eps, ptr(y_bf16),
-         ptr(y_f32), ptr(mean), ptr(rstd), stream_ptr())
+    # algorithmic bytes: the fp32 rows in, the normalised rows out (bf16 and / or fp32)
+    nbytes = rows * D * (4 + (2 if y_bf16 is not None else 0) + (4 if y_f32 is not None else 0))
+    _bracketed("layernorm_fwd", nbytes, lambda: call(
+        "devit_layernorm_fwd", ptr(x2d), rows, D, in_group, in_stride, ptr(gamma), ptr(beta), eps, ptr(y_bf16),
+        ptr(y_f32), ptr(mean), ptr(rstd), stream_ptr()))
 
 
 def layernorm_bwd(dy, dy_is_f32, x2d, rows, D, mean, rstd, gamma, dres, dx, dx_bf16, rowscale, rows_per_scale, dgamma,
                   dbeta, in_group=0, in_stride=0, gsum=None):
     nbytes = L.load().devit_layernorm_bwd_workspace(rows, D)
     ws = workspace(x2d.device, nbytes)
-    call("devit_layernorm_bwd", ptr(dy), int(dy_is_f32), ptr(x2d), rows, D, in_group, in_stride, ptr(mean), ptr(rstd),
-         ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(rowscale), rows_per_scale, ptr(dgamma), ptr(dbeta),
-         ptr(gsum), 1, ptr(ws), ws.numel(), stream_ptr())
+    # algorithmic bytes: dy, x and the incoming residual gradient in; the fp32 gradient (and its bf16 copy) out
+    nbytes = rows * D * ((4 if dy_is_f32 else 2) + 4 + (4 if dres is not None else 0) + (4 if dx is not None else 0) +
+                         (2 if dx_bf16 is not None else 0))
+    _bracketed("layernorm_bwd", nbytes, lambda: call(
+        "devit_layernorm_bwd", ptr(dy), int(dy_is_f32), ptr(x2d), rows, D, in_group, in_stride, ptr(mean), ptr(rstd),
+        ptr(gamma), ptr(dres), ptr(dx), ptr(dx_bf16), ptr(rowscale), rows_per_scale, ptr(dgamma), ptr(dbeta),
+        ptr(gsum), 1, ptr(ws), ws.numel(), stream_ptr()))
 
 
 def cast_bf16(src, dst=None):
@@ -203,8 +226,10 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
     linear_fwd(ln1, bp.qkv_w16, bp.qkv_b, M, out=qkv)
     attn_o = rows_alloc(M, Da, BF16, dev)
     lse = torch.empty((B, H, N), dtype=F32, device=dev) if need_grad else None
-    call("devit_attn_fwd", ptr(qkv), ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, N, H, Da // H, (Da // H) ** -0.5,
-         stream_ptr())
+    # algorithmic bytes: q, k, v in, the head outputs out (bf16)
+    _bracketed("attention_fwd", M * Da * 2 * 4, lambda: call(
+        "devit_attn_fwd", ptr(qkv), ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, N, H, Da // H, (Da // H) ** -0.5,
+        stream_ptr()))
     x1 = torch.empty((B, N, D), dtype=F32, device=dev)
     att = torch.empty((M, D), dtype=BF16, device=dev) if want_att else None
     dp1, dp2 = dp if dp is not None else (None, None)
@@ -260,8 +285,10 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, p
     linear_dgrad(g1, bp.proj_w16, M, out=dattn)
     linear_wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), None if fuse_pb else grad_buf(bp.proj_b), M)
     dqkv = rows_alloc(M, 3 * D, BF16, dev)
-    call("devit_attn_bwd", ptr(s["qkv"]), ptr(s["attn_o"]), ptr(dattn), ptr(s["lse"]), ptr(bp.head_gate),
-         ptr(dqkv_add), ptr(dqkv), B, N, H, D // H, (D // H) ** -0.5, stream_ptr())
+    # algorithmic bytes: q, k, v, o, do in; dq, dk, dv out (+ the relation-loss gradient that is added in)
+    _bracketed("attention_bwd", M * D * 2 * (8 + (3 if dqkv_add is not None else 0)), lambda: call(
+        "devit_attn_bwd", ptr(s["qkv"]), ptr(s["attn_o"]), ptr(dattn), ptr(s["lse"]), ptr(bp.head_gate),
+        ptr(dqkv_add), ptr(dqkv), B, N, H, D // H, (D // H) ** -0.5, stream_ptr()))
     dln1 = rows_alloc(M, D, BF16, dev)
     linear_dgrad(dqkv, bp.qkv_w16, M, out=dln1)
     linear_wgrad(dqkv, s["ln1"], grad_buf(bp.qkv_w), grad_buf(bp.qkv_b), M)
