@@ -155,6 +155,8 @@ def main():
             look.take(img)
         feed = iter(engine._PreparedBatches(_Repeat(host, args.warmup + args.steps), dev, None, look))
 
+    opt_events = None        # instrumented step: events around the optimizer tail (clip + AdamW + EMA + bf16 re-cast)
+
     def step():
         opt.zero_grad()
         t_out = None
@@ -168,8 +170,14 @@ def main():
         out = engine.distill_forward(student, teacher, x, y, gama=(0.2, 0.1, 0.3), criterion=criterion,
                                      teacher_outputs=t_out)
         out["loss"].backward()
+        if opt_events is not None:
+            opt_events.append(torch.cuda.Event(enable_timing=True))
+            opt_events[-1].record()
         reducer.finish()
         opt.step()
+        if opt_events is not None:
+            opt_events.append(torch.cuda.Event(enable_timing=True))
+            opt_events[-1].record()
         return out["loss"]
 
     def fence():
@@ -219,8 +227,11 @@ def main():
     step()
     torch.cuda.synchronize()
     ops.PROFILE, ops.PROFILE_HBM = [], []
+    opt_events = []
     step()
     torch.cuda.synchronize()
+    opt_tail_ms = opt_events[0].elapsed_time(opt_events[1])
+    opt_events = None
     recs, ops.PROFILE = ops.PROFILE, None
     hbm_recs, ops.PROFILE_HBM = ops.PROFILE_HBM, None
     # the bandwidth-bound kernels of the same serialized step: algorithmic bytes / event time (HBM peak 8 TB/s)
@@ -249,7 +260,8 @@ def main():
             "other_templates": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "launches": v[2],
                                     "ms_per_step": round(v[1] * 1e3, 3)} for k, v in by_t.items() if k != dom},
             "gemm_ms_per_step": round(sum(v[1] for v in by_t.values()) * 1e3, 3),
-            "in_two_stream_timed_region": two_stream, "hbm_bound_kernels": hbm}
+            "in_two_stream_timed_region": two_stream, "hbm_bound_kernels": hbm,
+            "optimizer_tail_ms_per_step": round(opt_tail_ms, 3)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
