@@ -103,6 +103,11 @@ def pmc_traffic():
 
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON; whatever the libraries print while starting up (RCCL's version banner
+    # at communicator creation, ...) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -199,7 +204,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    loss_value = float(loss)
+    loss_value = float(loss.detach())
     assert loss_value == loss_value, "non-finite loss"
     img_per_s = B * world * args.steps / dt
 
@@ -268,7 +273,7 @@ def main():
         cpu = cpu_baseline(args.cpu_seconds)
 
     if rank == 0:
-        print(json.dumps({
+        line = json.dumps({
             "metric": "images/sec distill_sub step (DeiT-B->dedeit, bs256, 224^2)", "value": round(img_per_s, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
@@ -277,7 +282,9 @@ def main():
             "config": {"workload": f"distill_sub step dedeit<-deit_base_distilled_patch16_224, num_division=4 "
                                    f"(C={C}), bs={B}/GPU, 224x224, hard distillation, drop_path 0.1, AdamW+EMA",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(loss_value, 5)},
-            "roofline": roof, "cpu_baseline": cpu}))
+            "roofline": roof, "cpu_baseline": cpu})
+        json_out.write(line + "\n")
+        json_out.flush()
     if world > 1:
         dist.destroy_process_group()
 
