@@ -600,18 +600,22 @@ void gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // Split-K weight gradient: the row sums of A (= dY^T, i.e. the bias gradient) come from the fragments the MFMAs
-    // read anyway -- one v_dot2c_f32_bf16 per two elements, on the waves that own the first 64 output columns of the
-    // first n-tile only (every A row is seen exactly once per k-slice there).
+    // read anyway -- one v_dot2c_f32_bf16 per two elements, on the waves that own the first 64 columns of their tile.
+    // The n-tiles of one (m-tile, k-slice) see the same A rows, so they share the work: tile tn takes the K-steps
+    // kt with kt % tiles_n == tn (every A element is added exactly once).
     float rsum[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) rsum[i] = 0.f;
-    const bool rowsum_on = KIND == DEVIT_EPI_ATOMIC_F32 && g.ep.aux != nullptr && ct.n0 == 0 && wn == 0;
+    const bool rowsum_on = KIND == DEVIT_EPI_ATOMIC_F32 && g.ep.aux != nullptr && wn == 0;
+    int rs_wait = 0;          // K-steps until this tile's next turn
+    if (rowsum_on) rs_wait = (ct.n0 / BN - ct.kt0 % g.tiles_n + g.tiles_n) % g.tiles_n;
 
     auto kstep = [&]() {
       const char* cur_a = smem + ca_slot * A_TILE_BYTES;
       const char* cur_b = smem + B_RING + cb_slot * B_TILE_BYTES;
       ca_slot = ca_slot + 1 == NA ? 0 : ca_slot + 1;
       cb_slot ^= 1;
+      const bool rs_now = KIND == DEVIT_EPI_ATOMIC_F32 && rowsum_on && rs_wait == 0;
 #ifdef DEVIT_GEMM_NOCOMPUTE   // diagnostic build: the fill pipeline alone
       if (g.K < 0)
 #endif
@@ -628,12 +632,13 @@ void gemm_kernel(const GemmArgs g) {
           for (int j = 0; j < NI; ++j)
             acc[i][j] = DIRECT ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
         if constexpr (KIND == DEVIT_EPI_ATOMIC_F32) {
-          if (rowsum_on) {
+          if (rs_now) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) rsum[i] = sum8_bf16(af[i], rsum[i]);
           }
         }
       }
+      if constexpr (KIND == DEVIT_EPI_ATOMIC_F32) rs_wait = rs_wait == 0 ? g.tiles_n - 1 : rs_wait - 1;
     };
     const devit_epilogue& ep = g.ep;
     const int nw = ct.n0 + wn * WN;
