@@ -7,6 +7,7 @@ bucketed RCCL gradient all-reduce, global-norm clip + AdamW + EMA + bf16 weight 
 the reference).  Inputs are synthetic and already resident in HBM; weights are random-init.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            (no launcher: starts its own N ranks, one per GPU, before touching a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -17,6 +18,8 @@ box's host cores on a bounded bs-8 sample of the same step.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -101,8 +104,73 @@ def pmc_traffic():
         return json.load(f).get("traffic_bytes_per_launch")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, the README.md:50-68 launch
+    form of the reference) as children of this process, which has not touched a GPU and never will; rank 0's JSON line
+    passes through on stdout, the exit code is the children's."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args, rank, world, json_out):
+    """DEVIT_BENCH_STUB=1 (tests/test_bench_launch.py): the launch / rendezvous / bucketed exchange / timing / one-line
+    protocol of this file on CPU tensors over gloo, with a toy model in place of the HIP step (no GPU in CI)."""
+    from devit_amd import ddp
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(rank)                         # ranks start different: the broadcast must fix it
+    model = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 8))
+    flat = ddp.FlatParams(model)
+    ddp.broadcast_parameters(flat)
+    reducer = ddp.BucketedGradReducer(flat, bucket_bytes=8192)
+    x = torch.randn(16, 32, generator=torch.Generator().manual_seed(100 + rank))
+    if os.environ.get("DEVIT_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                         # the launcher must turn one failed rank into a non-zero exit
+    params = list(model.parameters())
+
+    def step():
+        flat.zero_grad()
+        loss = model(x).square().mean()
+        grads = torch.autograd.grad(loss, params)
+        for p, g in reversed(list(zip(params, grads))):
+            p.grad.add_(g)
+            reducer.mark_ready([p])
+        reducer.finish()
+        flat.flat.add_(flat.flat_grad, alpha=-0.01 * flat.grad_scale)
+        flat.grad_scale = 1.0
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    w = [torch.zeros_like(flat.flat) for _ in range(world)]
+    dist.all_gather(w, flat.flat)
+    in_sync = all(torch.equal(w[0], t) for t in w)
+    if rank == 0:
+        json_out.write(json.dumps({"metric": "stub", "value": 16 * world * args.steps / float(tmax), "unit": "rows/sec",
+                                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                                   "data": "stub", "replicas_in_sync": in_sync, "buckets": len(reducer.buckets),
+                                   "loss": float(loss)}) + "\n")
+        json_out.flush()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))          # nothing above has initialised a GPU; the ranks are fresh processes
     # stdout carries exactly one line, the JSON; whatever the libraries print while starting up (RCCL's version banner
     # at communicator creation, ...) goes to stderr
     sys.stdout.flush()
@@ -111,11 +179,14 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("DEVIT_BENCH_STUB") == "1":
+        return stub_main(args, rank, world, json_out)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import devit_amd
@@ -130,8 +201,9 @@ def main():
     for p in teacher.parameters():
         p.requires_grad_(False)
 
-    flat = ddp.FlatParams(student).attach_bf16(student)
-    ddp.broadcast_parameters(flat)
+    flat = ddp.FlatParams(student)
+    ddp.broadcast_parameters(flat)          # before the bf16 GEMM copies are cast from the masters
+    flat.attach_bf16(student)
     reducer = ddp.BucketedGradReducer(flat).attach(student)
     opt = optim.FlatAdamW(flat, lr=5e-4 * B * world / 512.0, weight_decay=0.0, max_norm=1.0, ema_decay=0.99996)
     criterion = losses.DistillLoss(losses.SoftTargetCrossEntropy(), "hard", 0.5, 1.0)
@@ -208,6 +280,18 @@ def main():
     assert loss_value == loss_value, "non-finite loss"
     img_per_s = B * world * args.steps / dt
 
+    # ---- gradient exchange of one more step: summed bucket all-reduce time and the share of it that ran under backward
+    exchange = None
+    if world > 1:
+        reducer.timing = True
+        step()
+        reducer.timing = False
+        ar_ms, ov = reducer.timing_summary()
+        t = torch.tensor([ar_ms, ov], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                  # slowest rank's exchange, like the step time
+        exchange = {"allreduce_ms": round(float(t[0]), 3), "overlap_frac": round(float(ov), 3),
+                    "buckets": len(reducer.buckets), "bytes": flat.numel * 4}
+
     # ---- dominant-kernel roofline: extra instrumented steps, events on the launch stream ---------------------
     # (a) as in the timed region: the teacher's launches share the GPU with the student's (two streams), so an event
     #     bracket there also contains the other model's workgroups -- this is what a rocprofv3 average over the run sees
@@ -282,6 +366,8 @@ def main():
             "config": {"workload": f"distill_sub step dedeit<-deit_base_distilled_patch16_224, num_division=4 "
                                    f"(C={C}), bs={B}/GPU, 224x224, hard distillation, drop_path 0.1, AdamW+EMA",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(loss_value, 5)},
+            "allreduce_ms": exchange["allreduce_ms"] if exchange else None,
+            "overlap_frac": exchange["overlap_frac"] if exchange else None, "exchange": exchange,
             "roofline": roof, "cpu_baseline": cpu})
         json_out.write(line + "\n")
         json_out.flush()

@@ -55,7 +55,7 @@ SIGNATURES = {
     "devit_sgemm_small": (_I, [_P, _LL, _LL, _P, _LL, _LL, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "devit_sumsq_workspace": (_Z, []),
     "devit_sumsq_f32": (_I, [_P, _Z, _P, _P, _Z, _P]),
-    "devit_adamw_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "devit_adamw_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _F, _P]),
     "devit_cls_distill_loss": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "devit_token_mse": (_I, [_P, _P, _Z, _P, _P, _I, _P]),
     "devit_relation_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

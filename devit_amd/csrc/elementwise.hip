@@ -206,6 +206,7 @@ struct AdamArgs {
   float* p; const float* g; float* m; float* v; float* ema; __bf16* p_bf16;
   const float* gnorm_sq;  // device scalar: sum of squared grads (NULL = no clipping)
   const float* dyn;       // device [3]: lr, 1 - beta1^step, 1 - beta2^step (changes every step; graph-safe)
+  const unsigned char* no_decay4;   // one byte per 4-element granule: != 0 -> no weight decay there (NULL: decay all)
   size_t n;
   float beta1, beta2, eps, wd, max_norm, ema_decay, grad_scale;
 };
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
     f32x4 p = *(const f32x4*)(a.p + i * 4);
     const f32x4 g = *(const f32x4*)(a.g + i * 4) * clip;
     f32x4 m = *(const f32x4*)(a.m + i * 4), v = *(const f32x4*)(a.v + i * 4);
-    p *= (1.0f - lr * a.wd);
+    if (!(a.no_decay4 && a.no_decay4[i])) p *= (1.0f - lr * a.wd);
     m = a.beta1 * m + (1.0f - a.beta1) * g;
     v = a.beta2 * v + (1.0f - a.beta2) * g * g;
 #pragma unroll
@@ -372,13 +373,15 @@ extern "C" int devit_sumsq_f32(const float* g, size_t n, float* out, void* works
 }
 
 extern "C" int devit_adamw_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
-                                const float* gnorm_sq, const float* dyn, size_t n, float beta1, float beta2, float eps,
+                                const unsigned char* no_decay4, const float* gnorm_sq, const float* dyn, size_t n,
+                                float beta1, float beta2, float eps,
                                 float weight_decay, float max_norm, float ema_decay, float grad_scale,
                                 void* stream) {
   DEVIT_CHECK(p && g && m && v && dyn, DEVIT_ERR_ARG, "devit_adamw_step: bad argument");
   DEVIT_CHECK(n % 4 == 0, DEVIT_ERR_SHAPE, "devit_adamw_step: n must be a multiple of 4 (pad the flat buffer)");
   AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.ema = ema; a.p_bf16 = (__bf16*)p_bf16; a.gnorm_sq = gnorm_sq; a.n = n;
+  a.no_decay4 = no_decay4;
   a.dyn = dyn; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
   a.max_norm = max_norm; a.ema_decay = ema_decay; a.grad_scale = grad_scale;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, a);

@@ -7,7 +7,9 @@ Design (MI355X: 8 GPUs fully connected by xGMI, ring all-reduce is per-link boun
   * the model's autograd nodes report finished parameter groups (`grad_ready` callback: heads, each block,
     embeddings); when the last parameter of a bucket is reported the bucket's all-reduce is launched on a
     side stream (after an event recorded on the compute stream), so it runs under the remaining backward;
-  * `finish()` joins the side stream before grad-clip / optimizer, and scales by 1 / world_size (mean, like DDP);
+  * `finish()` joins the side stream before grad-clip / optimizer.  The buckets hold SUMS; the 1 / world_size of DDP's
+    mean is `FlatParams.grad_scale`, which the fused optimizer kernel folds into its clip factor (devit_adamw_step's
+    `grad_scale`) -- no extra pass over the 87 MB gradient buffer;
   * the teacher is frozen and replicated: no traffic.  87.4 MB fp32 per step at C = 250.
 The same code runs on CPU tensors with the gloo backend (tests/test_ddp_gloo.py).
 """
@@ -41,19 +43,34 @@ class FlatParams:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
         self.index = {id(p): i for i, p in enumerate(ordered)}
         self.flat16 = None
+        self._w16_mods = []
+        # flat_grad holds (true gradient) / grad_scale: 1 normally, 1 / world_size after a summing all-reduce
+        # (BucketedGradReducer.finish); consumed by optim.FlatAdamW.step
+        self.grad_scale = 1.0
 
     def attach_bf16(self, model):
         """Keep ONE flat bf16 copy of all parameters (rewritten by the fused optimizer kernel every step) and point
         the GEMM weight caches of the model's Linear / Conv2d children at views of it."""
-        from . import ops
-        self.flat16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
-        ops.cast_bf16(self.flat, self.flat16)
-        for mod in model.modules():
-            w = getattr(mod, "weight", None)
-            if isinstance(mod, (torch.nn.Linear, torch.nn.Conv2d)) and w is not None and id(w) in self.index:
-                o = self.offsets[self.index[id(w)]]
-                mod._w16 = (w._version, self.flat16[o:o + w.numel()].view(w.shape[0], -1), w.data_ptr())
+        if self.flat16 is None:
+            self.flat16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
+        self._w16_mods = [mod for mod in model.modules()
+                          if isinstance(mod, (torch.nn.Linear, torch.nn.Conv2d)) and getattr(mod, "weight", None) is not None
+                          and id(mod.weight) in self.index]
+        self.refresh_bf16()
         return self
+
+    def refresh_bf16(self):
+        """Re-cast the flat bf16 copy from the fp32 masters and re-stamp the modules' GEMM weight caches.  Needed after
+        anything that rewrites the masters behind the parameters' version counters (the initial broadcast writes
+        `flat` in place; `p.data = view` keeps each parameter's own counter), and after load_state_dict."""
+        if self.flat16 is None:
+            return
+        from . import ops
+        ops.cast_bf16(self.flat, self.flat16)
+        for mod in self._w16_mods:
+            w = mod.weight
+            o = self.offsets[self.index[id(w)]]
+            mod._w16 = (w._version, self.flat16[o:o + w.numel()].view(w.shape[0], -1), w.data_ptr())
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -103,12 +120,17 @@ class RcclComm:
 
 
 class BucketedGradReducer:
-    """All-reduce (mean) of FlatParams.flat_grad in buckets, fired from `grad_ready` callbacks."""
+    """All-reduce (sum) of FlatParams.flat_grad in buckets, fired from `grad_ready` callbacks.
 
-    def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, process_group=None, comm=None):
-        """comm: an RcclComm -> the buckets go through the C ABI's communicator instead of torch.distributed's."""
+    comm: anything with `.world` and `.all_reduce(flat_f32_view, stream=)` (RcclComm, or a recording stand-in in the
+    tests) -> the buckets go through it instead of torch.distributed."""
+
+    def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, process_group=None, comm=None, world=None):
         self.flat, self.group, self.comm = flat, process_group, comm
-        self.world = comm.world if comm is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        if world is not None:
+            self.world = world
+        else:
+            self.world = comm.world if comm is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         # bucket boundaries on parameter boundaries, in flat (= reverse forward) order
         self.buckets, start, last = [], 0, 0
         limit = bucket_bytes // 4
@@ -123,11 +145,16 @@ class BucketedGradReducer:
                 self.bucket_of[i] = b
         self.cuda = flat.flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
+        self.timing = False          # bench.py: record events around every bucket (allreduce_ms / overlap_frac)
+        self.last_timing = None
         self.reset()
 
     def reset(self):
         self.pending = [p1 - p0 + 1 for (_, _, p0, p1) in self.buckets]
+        self.reported = set()
         self.handles, self.launched = [], [False] * len(self.buckets)
+        self.launch_order = []
+        self._events = []
 
     def attach(self, model):
         """Route the model's grad_ready callbacks here (VisionTransformer.grad_ready)."""
@@ -139,6 +166,10 @@ class BucketedGradReducer:
             i = self.flat.index.get(id(p))
             if i is None:
                 continue
+            if i in self.reported:
+                raise RuntimeError(f"BucketedGradReducer: parameter {self.flat.names[i]} was reported twice in one backward "
+                                   "(its bucket may already be in flight)")
+            self.reported.add(i)
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0 and not self.launched[b]:
@@ -146,6 +177,7 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         self.launched[b] = True
+        self.launch_order.append(b)
         if self.world == 1:
             return
         s, e, _, _ = self.buckets[b]
@@ -154,16 +186,33 @@ class BucketedGradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())          # backward kernels of this bucket are enqueued
             self.stream.wait_event(ev)
-            if self.comm is not None:
-                self.comm.all_reduce(view, stream=self.stream)
-                return
             with torch.cuda.stream(self.stream):
-                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                if self.comm is not None:
+                    self.comm.all_reduce(view, stream=self.stream)
+                else:
+                    # the collective runs on the process group's own stream, ordered after this side stream; wait() makes
+                    # the side stream (not the host) wait for it, so that `finish` only has to join the side stream
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+                if self.timing:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._events.append((b, e0, e1))
+        elif self.comm is not None:
+            self.comm.all_reduce(view, stream=None)
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self):
-        """Launch whatever was never reported (unused parameters), wait, and turn sums into means."""
+    def finish(self, average=False):
+        """Launch whatever was never reported (unused parameters) and join.  The buffer then holds SUMS over ranks and
+        `flat.grad_scale` = 1 / world says so (the optimizer kernel applies it); average=True scales in place instead
+        (an extra pass; for callers that read `.grad` themselves)."""
+        end_bwd = None
+        if self.cuda and self.timing and self.world > 1:
+            end_bwd = torch.cuda.Event(enable_timing=True)
+            end_bwd.record()                                  # backward is enqueued up to here on the compute stream
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
@@ -171,12 +220,62 @@ class BucketedGradReducer:
             h.wait()
         if self.cuda and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.stream)
-        if self.world > 1:
+        self.flat.grad_scale = 1.0 / self.world
+        if average and self.world > 1:
             self.flat.flat_grad.mul_(1.0 / self.world)
+            self.flat.grad_scale = 1.0
+        if end_bwd is not None:
+            self.last_timing = (self._events, end_bwd)
+        order = self.launch_order
         self.reset()
+        return order
+
+    def timing_summary(self):
+        """(allreduce_ms, overlap_frac) of the last finished step recorded with `timing = True`: the summed bucket
+        all-reduce durations (events on the exchange stream) and the share of that time that ran before the last
+        backward kernel was done (events on the compute stream).  Synchronises."""
+        if self.last_timing is None:
+            return None
+        events, end_bwd = self.last_timing
+        torch.cuda.synchronize()
+        base = events[0][1]
+        t_bwd = base.elapsed_time(end_bwd)
+        total = hidden = 0.0
+        for _, e0, e1 in events:
+            t0, t1 = base.elapsed_time(e0), base.elapsed_time(e1)
+            total += t1 - t0
+            hidden += max(0.0, min(t1, t_bwd) - min(t0, t_bwd))
+        return total, (hidden / total if total > 0 else 0.0)
 
 
 def broadcast_parameters(flat: FlatParams, src=0, group=None):
     """DDP's initial parameter broadcast (C4): one collective over the flat master buffer."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat.flat, src=src, group=group)
+        flat.refresh_bf16()     # the in-place write does not bump the parameters' version counters (_w16 cannot notice)
+
+
+def allreduce_mean_(tensors, group=None):
+    """In-place mean over ranks of a list of tensors (one coalesced collective): the gradient exchange of the small
+    non-flat models (ensemble.py's MultiViT / EnsMLP), DistributedDataParallel's job at ensemble.py:332-334."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    tensors = [t for t in tensors if t is not None]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).float() for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / dist.get_world_size(group))
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+
+
+def broadcast_module(module, src=0, group=None):
+    """DDP's initial parameter / buffer broadcast for a module that is not flat-packed."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)

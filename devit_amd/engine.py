@@ -304,6 +304,9 @@ def train_1epoch_ens_disjoint(model, ens_model, criterion, data_loader, optimize
         ens_optimizer.zero_grad(set_to_none=True)
         out = ens_forward(model, ens_model, criterion, samples, targets, args.distillation_type)
         out['loss'].backward()
+        # the gradient mean DistributedDataParallel produces for both wrapped models (ensemble.py:332-334); no-op at world 1
+        from . import ddp
+        ddp.allreduce_mean_([p.grad for p in model.parameters()] + [p.grad for p in ens_model.parameters()])
         if max_norm:
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
             torch.nn.utils.clip_grad_norm_(ens_model.parameters(), max_norm)

@@ -7,13 +7,30 @@ from . import _lib as L
 from ._lib import call, ptr, stream_ptr
 
 
-class FlatAdamW:
-    """AdamW over ddp.FlatParams.  `weight_decay` is uniform (distill_sub.py:73 default 0)."""
+def no_decay_names(model):
+    """Parameters timm's create_optimizer (distill_sub.py:340) puts into its weight_decay = 0 group whenever
+    weight_decay > 0: 1-D tensors, `.bias`, and the names in model.no_weight_decay()."""
+    skip = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
+    return {n for n, p in model.named_parameters()
+            if p.requires_grad and (p.ndim <= 1 or n.endswith(".bias") or n in skip)}
 
-    def __init__(self, flat, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None, ema_decay=None):
+
+class FlatAdamW:
+    """AdamW over ddp.FlatParams.  `no_decay`: parameter names exempt from weight decay (see no_decay_names; every
+    tensor starts on a 4-element granule of the flat buffer, so the exemption is one byte per granule)."""
+
+    def __init__(self, flat, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None, ema_decay=None,
+                 no_decay=None):
         self.flat, self.betas, self.eps, self.weight_decay = flat, betas, eps, weight_decay
         self.max_norm, self.ema_decay = max_norm, ema_decay
         dev = flat.flat.device
+        self.no_decay4 = None
+        if weight_decay and no_decay:
+            mask = torch.zeros(flat.numel // 4, dtype=torch.uint8)
+            for name, p, o in zip(flat.names, flat.params, flat.offsets):
+                if name in no_decay:
+                    mask[o // 4:(o + p.numel() + 3) // 4] = 1
+            self.no_decay4 = mask.to(dev)
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
         self.ema = flat.flat.clone() if ema_decay is not None else None
@@ -43,9 +60,12 @@ class FlatAdamW:
         if clip:
             call("devit_sumsq_f32", ptr(f.flat_grad), f.numel, ptr(self.gnorm_sq), ptr(self._ws), self._ws.numel(),
                  stream_ptr())
+        # f.grad_scale: 1 / world after the summing bucket all-reduce (ddp.BucketedGradReducer.finish) -- the mean of DDP
         call("devit_adamw_step", ptr(f.flat), ptr(f.flat_grad), ptr(self.m), ptr(self.v), ptr(self.ema), ptr(f.flat16),
-             ptr(self.gnorm_sq) if clip else None, ptr(self._dyn), f.numel, b1, b2, self.eps, self.weight_decay,
-             float(self.max_norm or 0.0), float(self.ema_decay or 0.0), 1.0, stream_ptr())
+             ptr(self.no_decay4), ptr(self.gnorm_sq) if clip else None, ptr(self._dyn), f.numel, b1, b2, self.eps,
+             self.weight_decay, float(self.max_norm or 0.0), float(self.ema_decay or 0.0), float(f.grad_scale),
+             stream_ptr())
+        f.grad_scale = 1.0
 
     def ema_state_dict(self, model):
         """EMA weights keyed like model.state_dict() (timm get_state_dict(model_ema), distill_sub.py:429)."""

@@ -22,7 +22,7 @@ import torch
 from . import ops
 
 __all__ = ["compact", "uncompact", "compact_block_weights", "compacted_gflops", "masks_from_sparsity", "load_policy",
-           "get_policy", "save_gates", "load_gates"]
+           "get_policy", "save_gates", "load_gates", "read_shrink_checkpoint", "rank_units", "apply_shrink"]
 
 
 def _round_up(n, m):
@@ -151,3 +151,96 @@ def save_gates(model, path):
 
 def load_gates(model, path):
     load_policy(model, [(torch.from_numpy(h), torch.from_numpy(n)) for h, n in torch.load(path, weights_only=False)])
+
+
+# ------------------------------------------------------------------------------------------------------
+# the training CLI's shrink step (distill_sub.py:383-401): policy files -> one-batch importance ranking -> gates
+# ------------------------------------------------------------------------------------------------------
+def read_shrink_checkpoint(path):
+    """distill_sub.py:384-389: `shrinked_policy.npy` [population, 24 or 25] and `shrinked_accuracy.npy` [population]
+    written by the reference's shrink.py:417-418; the best-accuracy row gives 12 neuron ratios (columns 0..11) and the
+    head ratios.  The reference slices the heads as `[12:-1]` -- 11 values from a 24-column file, so its attn_head_mask
+    would run out at the last block: columns 12..23 are used here whether the file has 24 or 25."""
+    import os
+    import numpy as np
+    policy = np.load(os.path.join(path, 'shrinked_policy.npy'))
+    acc = np.load(os.path.join(path, 'shrinked_accuracy.npy'))
+    if policy.ndim != 2 or policy.shape[1] not in (24, 25) or policy.shape[0] != acc.reshape(-1).shape[0]:
+        raise ValueError(f"shrink checkpoint {path}: policy {policy.shape} / accuracy {acc.shape} are not [pop, 24|25] / [pop]")
+    row = policy[int(np.argmax(acc))]
+    return row[:12].astype(float), row[12:24].astype(float)
+
+
+def _center(K):
+    return K - K.mean(-2, keepdim=True) - K.mean(-1, keepdim=True) + K.mean((-2, -1), keepdim=True)
+
+
+def _gauss_mix(x):
+    """core/imp_rank.py:182-192,229: mean of five Gaussian kernels (sigma 1, 2, 4, 8, 16) on the rows of x [..., B, F]."""
+    inner = x @ x.transpose(-1, -2)
+    nrm = torch.diagonal(inner, dim1=-2, dim2=-1)
+    d2 = nrm.unsqueeze(-1) + nrm.unsqueeze(-2) - 2 * inner
+    return sum(torch.exp(-d2 / (2.0 * s * s)) for s in (1.0, 2.0, 4.0, 8.0, 16.0)) / 5.0
+
+
+def _hsic(x, y, y_kernel, mean_sub):
+    """core/imp_rank.py:203-239 (HSICLoss.forward), batched over leading dims of x.  x [..., B, F], y [B, C] or
+    [..., B, F'].  `x - mean / (std + 1e-12)` keeps the reference's operator precedence."""
+    if mean_sub:
+        x = x - x.mean(-2, keepdim=True) / (x.std(-2, keepdim=True) + 1e-12)
+        y = y - y.mean(-2, keepdim=True)
+    gx = _center(_gauss_mix(x))
+    gy = _center(y @ y.transpose(-1, -2)) if y_kernel == 'linear' else _center(_gauss_mix(y))
+    return (gx * gy.transpose(-1, -2)).sum((-2, -1))         # trace(G_X G_Y)
+
+
+@torch.no_grad()
+def rank_units(model, data_loader, device=None):
+    """One-batch importance ranking of every block's MLP neurons and attention heads (core/imp_rank.py:16-47 and
+    :93-129): neurons by 0.1 * HSIC(activation, softmax(logits)) + 0.9 * |activation| mass, both min-max normalised;
+    heads by relevance - 0.1 * mean redundancy against the other heads.  Reads the `neuron_output` / `head_output` the
+    forward leaves on the modules (post-gate values).  Returns (neuron_rank, head_rank): per block an
+    ascending argsort (numpy), the input of masks_from_sparsity.  Host-side torch arithmetic: a one-off setup step."""
+    import numpy as np
+    data, _ = next(iter(data_loader))
+    if device is not None:
+        data = data.to(device)
+    was_training = model.training
+    model.eval()
+    out = model(data)
+    out = (out[0] + out[1]) / 2 if isinstance(out, tuple) else out
+    prob = torch.softmax(out.float(), dim=-1)
+    neuron_rank, head_rank = [], []
+    for blk in _blocks(model):
+        X = blk.mlp.neuron_output.float()                           # [B, N, hidden]
+        hs = _hsic(X.permute(2, 0, 1), prob, 'linear', True)        # one HSIC per neuron over [B, N] features
+        hs = (hs - hs.min()) / (hs.max() - hs.min())
+        act = X.abs().sum((0, 1))
+        act = (act - act.min()) / (act.max() - act.min())
+        neuron_rank.append(np.argsort((0.1 * hs + 0.9 * act).cpu().numpy()))
+        Hh = blk.attn.head_output.float().mean(-1).permute(2, 0, 1)  # [H, B, N]: mean over the head's 64 channels
+        relv = _hsic(Hh, prob, 'linear', True)
+        nH = Hh.shape[0]
+        red = torch.stack([sum(_hsic(Hh[a], Hh[b], 'rbf', False) for b in range(nH) if b != a) / (nH - 1) for a in range(nH)])
+        head_rank.append(np.argsort((relv - 0.1 * red).cpu().numpy()))
+    model.train(was_training)
+    return neuron_rank, head_rank
+
+
+def apply_shrink(model, data_loader, shrink_checkpoint, neuron_shrinking, head_shrinking, device=None):
+    """distill_sub.py:383-401.  Returns the (head_mask, neuron_mask) policy it set.  A flag that cannot be honoured
+    raises -- the reference dies on an undefined `neuron_sparsity` when --neuron_shrinking comes without
+    --shrink_checkpoint; it never trains dense silently."""
+    if not (neuron_shrinking or head_shrinking):
+        return None
+    if not shrink_checkpoint:
+        raise ValueError("--neuron_shrinking / --head_shrinking need --shrink_checkpoint DIR holding shrinked_policy.npy and "
+                         "shrinked_accuracy.npy (the reference reads the sparsity ratios from there, distill_sub.py:384-389)")
+    neuron_sparsity, head_sparsity = read_shrink_checkpoint(shrink_checkpoint)
+    neuron_rank, head_rank = rank_units(model, data_loader, device)
+    blocks = _blocks(model)
+    zeros = [0.0] * len(blocks)
+    policy = masks_from_sparsity(model, neuron_sparsity if neuron_shrinking else zeros,
+                                 head_sparsity if head_shrinking else zeros, neuron_rank, head_rank)
+    load_policy(model, policy)
+    return policy

@@ -88,8 +88,10 @@ class SyntheticLoader:
         return self.steps
 
     def __iter__(self):
+        # fresh tensors every step, like a DataLoader: Mixup's cutmix branch writes into its input in place, and the
+        # look-ahead teacher forward of step k+1 is still reading its batch while step k runs
         for _ in range(self.steps):
-            yield self.img, self.lab
+            yield self.img.clone(), self.lab.clone()
 
 
 class Mixup:
@@ -131,18 +133,21 @@ class CosineEpochs:
             lr = a.warmup_lr + (self.base - a.warmup_lr) * epoch / max(a.warmup_epochs, 1)
         else:
             lr = a.min_lr + 0.5 * (self.base - a.min_lr) * (1 + math.cos(math.pi * epoch / max(a.epochs, 1)))
-        self.opt.param_groups[0]['lr'] = lr
+        for g in self.opt.param_groups:
+            g['lr'] = lr
 
     def step(self, epoch):
+        """timm Scheduler.step(epoch) as called after each epoch (distill_sub.py:421): the LR becomes f(epoch), so the
+        schedule runs one epoch behind the epoch counter -- epochs 0 and 1 both train at f(0) = warmup_lr.  Kept."""
         self.last = epoch
-        self._set(epoch + 1)
+        self._set(epoch)
 
     def state_dict(self):
         return {'last': self.last}
 
     def load_state_dict(self, sd):
         self.last = sd['last']
-        self._set(self.last + 1)
+        self._set(max(self.last, 0))
 
 
 class StepRunner:
@@ -154,7 +159,7 @@ class StepRunner:
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
         loss.backward()
-        self.reducer.finish()
+        self.reducer.finish()            # buckets hold sums; flat.grad_scale = 1 / world goes into the optimizer kernel
         optimizer.max_norm = clip_grad
         optimizer.step()
 
@@ -165,8 +170,22 @@ class StepRunner:
         pass
 
 
+def check_supported(args):
+    """Flags the reference hands to timm factories that this build implements for one value only: refuse the others
+    instead of silently training something else (create_optimizer / create_scheduler, distill_sub.py:340-343)."""
+    if args.opt.lower() != 'adamw':
+        raise SystemExit(f"--opt {args.opt}: only adamw (the reference's default) is built on the fused optimizer kernel")
+    if args.sched != 'cosine':
+        raise SystemExit(f"--sched {args.sched}: only cosine (the reference's default) is implemented")
+    if args.lr_noise is not None:
+        raise SystemExit("--lr-noise is not implemented")
+    if getattr(args, 'distillation_token', False):
+        raise SystemExit("--distillation-token (resize_dim models, models/de_vit.py:198-201) is outside the DEKD path")
+
+
 def main(args):
     utils.init_distributed_mode(args)
+    check_supported(args)
     args.method = 'distill_sub'
     args.name = (f'lr{args.lr}-bs{args.batch_size}-epochs{args.epochs}-grad{args.clip_grad}'
                  f'-wd{args.weight_decay}-wm{args.warmup_epochs}-gama{args.gama[0]}_{args.gama[1]}_{args.gama[2]}')
@@ -213,13 +232,15 @@ def main(args):
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
 
-    flat = ddp.FlatParams(model).attach_bf16(model)
-    ddp.broadcast_parameters(flat)
+    flat = ddp.FlatParams(model)
+    ddp.broadcast_parameters(flat)          # ranks are seeded seed + rank: rank 0's weights first, then the bf16 copies
+    flat.attach_bf16(model)
     reducer = ddp.BucketedGradReducer(flat).attach(model)
     args.lr = args.lr * args.batch_size * utils.get_world_size() / 512.0             # distill_sub.py:338
     optimizer = optim.FlatAdamW(flat, lr=args.lr, eps=args.opt_eps, betas=tuple(args.opt_betas or (0.9, 0.999)),
                                 weight_decay=args.weight_decay, max_norm=args.clip_grad,
-                                ema_decay=args.model_ema_decay if args.model_ema else None)
+                                ema_decay=args.model_ema_decay if args.model_ema else None,
+                                no_decay=optim.no_decay_names(model))       # timm's two parameter groups
     loss_scaler, lr_scheduler = StepRunner(reducer), CosineEpochs(optimizer, args)
     base = losses.SoftTargetCrossEntropy() if mixup_fn is not None else torch.nn.CrossEntropyLoss()
     criterion = losses.DistillLoss(base, args.distillation_type, args.distillation_alpha, args.distillation_tau)
@@ -228,8 +249,8 @@ def main(args):
     if args.resume:
         ck = torch.load(args.resume, map_location='cpu', weights_only=False)   # holds the argparse Namespace, like the reference's
         model.load_state_dict(ck['model'])
-        flat.attach_bf16(model)
-        if not args.eval and 'optimizer' in ck:
+        flat.refresh_bf16()
+        if not args.eval and not args.finetune and 'optimizer' in ck and 'lr_scheduler' in ck and 'epoch' in ck:
             optimizer.load_state_dict(ck['optimizer'])
             lr_scheduler.load_state_dict(ck['lr_scheduler'])
             args.start_epoch = ck['epoch'] + 1
@@ -237,7 +258,19 @@ def main(args):
         print(engine.evaluate(val_loader, model, device))
         return
 
-    output_dir, max_accuracy, start = Path(args.output_dir), 0.0, time.time()
+    # distill_sub.py:383-401: gate the student from a shrink policy before training
+    if args.shrink_checkpoint or args.neuron_shrinking or args.head_shrinking:
+        from devit_amd import shrink
+        policy = shrink.apply_shrink(model, train_loader, args.shrink_checkpoint, args.neuron_shrinking,
+                                     args.head_shrinking, device)
+        if policy is not None:
+            print("shrink: heads kept per block", [int(h.sum()) for h, _ in policy],
+                  "neurons kept per block", [int(n.sum()) for _, n in policy])
+
+    # distill_sub.py:403-404: everything of this division goes under sub-dataset{start_division}/ -- where ensemble.py
+    # (:228) looks for `{model-path}/sub-dataset{i}/checkpoint.pth`
+    output_dir, max_accuracy, start = Path(args.output_dir) / f'sub-dataset{args.start_division}', 0.0, time.time()
+    output_dir.mkdir(parents=True, exist_ok=True)
     for epoch in range(args.start_epoch, args.epochs):
         train_stats = engine.train_1epoch_qkv(model=model, teacher_model=teacher, criterion=criterion, args=args,
                                               data_loader=train_loader, optimizer=optimizer, device=device, epoch=epoch,
@@ -256,6 +289,9 @@ def main(args):
                 torch.save(model.state_dict(), output_dir / 'checkpoint.pth')
                 torch.save(args, output_dir / 'training_args.bin')
                 (output_dir / 'result.txt').write_text(f'Final Accuracy: {max_accuracy}\n')
+                if args.shrink_checkpoint:       # the gates are not in state_dict(): side-car file
+                    from devit_amd import shrink
+                    shrink.save_gates(model, output_dir / 'gates.pt')
         if utils.is_main_process():
             with (output_dir / "log.txt").open("a") as f:
                 f.write(json.dumps({**{f'train_{k}': v for k, v in train_stats.items()},

@@ -19,7 +19,7 @@ import torch
 
 import devit_amd
 import distill_sub as ds
-from devit_amd import engine, losses, utils
+from devit_amd import ddp, engine, losses, optim, utils
 from devit_amd.de_vit import model_config
 from devit_amd.ensemble_models import EnsMLP, MultiViT, load_sub_checkpoints
 
@@ -27,7 +27,13 @@ from devit_amd.ensemble_models import EnsMLP, MultiViT, load_sub_checkpoints
 def get_args_parser():
     base = ds.get_args_parser()
     p = argparse.ArgumentParser('DeViT Ensemble script (MI355X)', add_help=False, parents=[base], conflict_handler='resolve')
+    # defaults where ensemble.py differs from distill_sub.py (ensemble.py:39-41,47,68,72,77)
     p.add_argument('--lr', type=float, default=1e-5, metavar='LR')
+    p.add_argument('--epochs', default=3, type=int)
+    p.add_argument('--eval-batch-size', default=10, type=int)
+    p.add_argument('--clip-grad', type=float, default=None, metavar='NORM')
+    p.add_argument('--weight-decay', type=float, default=0.05)
+    p.add_argument('--model-path', type=str, default=r'./ckpt')
     p.add_argument('--no-aug', action='store_true', help='not use aug')
     p.add_argument('--loss', default='mse', choices=['mse', 'kldiv'], type=str, help="loss type")
     p.add_argument('--dataset', default='cifar100', choices=['cifar100', 'IMNET', 'INAT', 'INAT19'])
@@ -64,8 +70,19 @@ def get_models(args, num_subs, sub_classes, num_classes):
     return teacher, model.to(args.device), ens_model.to(args.device)
 
 
+def param_groups(module, weight_decay):
+    """timm create_optimizer's grouping (ensemble.py:341-342): no decay for 1-D tensors, biases, no_weight_decay()."""
+    skip = optim.no_decay_names(module)
+    named = [(n, p_) for n, p_ in module.named_parameters() if p_.requires_grad]
+    if not weight_decay:
+        return [{'params': [p_ for _, p_ in named], 'weight_decay': 0.0}]
+    return [{'params': [p_ for n, p_ in named if n not in skip], 'weight_decay': weight_decay},
+            {'params': [p_ for n, p_ in named if n in skip], 'weight_decay': 0.0}]
+
+
 def main(args):
     utils.init_distributed_mode(args)
+    ds.check_supported(args)
     device = torch.device(args.device)
     torch.manual_seed(args.seed + utils.get_rank())
     np.random.seed(args.seed + utils.get_rank())
@@ -90,9 +107,14 @@ def main(args):
                   f"hidden widths run {sorted(set(r[3] for r in rep))}")
         print(engine.evaluate_ens_disjoint(val_loader, model, ens_model, device))
         return
-    lr = args.lr * args.batch_size * utils.get_world_size() / 512.0
-    optimizer = torch.optim.AdamW(model.parameters(), lr=lr, eps=args.opt_eps, weight_decay=args.weight_decay)
-    ens_optimizer = torch.optim.AdamW(ens_model.parameters(), lr=lr, eps=args.opt_eps, weight_decay=args.weight_decay)
+    # ranks are seeded seed + rank: every replica starts from rank 0's weights, as under DistributedDataParallel
+    ddp.broadcast_module(model)
+    ddp.broadcast_module(ens_model)
+    args.lr = args.lr * args.batch_size * utils.get_world_size() / 512.0                      # ensemble.py:339-340
+    betas = tuple(args.opt_betas or (0.9, 0.999))
+    optimizer = torch.optim.AdamW(param_groups(model, args.weight_decay), lr=args.lr, eps=args.opt_eps, betas=betas)
+    ens_optimizer = torch.optim.AdamW(param_groups(ens_model, args.weight_decay), lr=args.lr, eps=args.opt_eps, betas=betas)
+    lr_scheduler, ens_lr_scheduler = ds.CosineEpochs(optimizer, args), ds.CosineEpochs(ens_optimizer, args)   # :345-346
     base = losses.SoftTargetCrossEntropy() if mixup_fn is not None else torch.nn.CrossEntropyLoss()
     criterion = losses.EnsLoss(base, teacher, args.model, args.distillation_type, args.distillation_alpha,
                                args.distillation_tau, args.loss)
@@ -101,9 +123,12 @@ def main(args):
         train_stats = engine.train_1epoch_ens_disjoint(model, ens_model, criterion, train_loader, optimizer, ens_optimizer,
                                                        device, epoch, None, args, None, mixup_fn=mixup_fn,
                                                        max_norm=args.clip_grad)
+        lr_scheduler.step(epoch)                                                                # ensemble.py:384-385
+        ens_lr_scheduler.step(epoch)
         utils.save_on_master({'model': model.state_dict(), 'ens_model': ens_model.state_dict(),
                               'optimizer': optimizer.state_dict(), 'ens_optimizer': ens_optimizer.state_dict(),
-                              'epoch': epoch, 'args': args}, output_dir / 'checkpoint_temp.pth')
+                              'lr_scheduler': lr_scheduler.state_dict(), 'ens_lr_scheduler': ens_lr_scheduler.state_dict(),
+                              'epoch': epoch, 'scaler': {}, 'args': args}, output_dir / 'checkpoint_temp.pth')
         test_stats = engine.evaluate_ens_disjoint(val_loader, model, ens_model, device)
         print(f"Epoch: {epoch}/{args.epochs} [Train] Loss: {train_stats.get('loss', float('nan')):.4f} "
               f"[Eval] Top-1: {test_stats['acc1']:.4f} Top-5: {test_stats['acc5']:.4f}")

@@ -179,12 +179,16 @@ int devit_sgemm_small(const float* A, long long sam, long long sak, const float*
  *   g *= grad_scale * min(1, max_norm / (||g|| + 1e-6));  AdamW;  ema = ema*d + (1-d)*p;  p_bf16 = bf16(p)
  * dyn = device float[3] {lr, 1 - beta1^step, 1 - beta2^step} (device-resident so a captured graph can
  * be replayed while the schedule advances).  gnorm_sq == NULL: no clipping.  n % 4 == 0.
+ * no_decay4: one byte per 4-element granule of the flat buffer, non-zero = exempt from weight decay (timm
+ * create_optimizer's second parameter group: 1-D tensors, biases, model.no_weight_decay(); distill_sub.py:340); NULL =
+ * decay everywhere.  grad_scale: the 1 / world_size of the data-parallel mean (the buckets are all-reduced as sums).
  * ---------------------------------------------------------------------------------------- */
 size_t devit_sumsq_workspace(void);
 int devit_sumsq_f32(const float* g, size_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
-int devit_adamw_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16, const float* gnorm_sq,
-                     const float* dyn, size_t n, float beta1, float beta2, float eps, float weight_decay,
-                     float max_norm, float ema_decay, float grad_scale, void* stream);
+int devit_adamw_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                     const unsigned char* no_decay4, const float* gnorm_sq, const float* dyn, size_t n, float beta1,
+                     float beta2, float eps, float weight_decay, float max_norm, float ema_decay, float grad_scale,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * DEKD logit loss + gradient in one launch.  Replaces DistillLoss.forward (utils/losses.py:156-177)

@@ -28,7 +28,14 @@ def _worker(rank, world, port, q):
             for p in model.parameters():
                 p.add_(1.0)
     flat = ddp.FlatParams(model)
+    # the bf16 GEMM copies are cast by the HIP library on the GPU; here a torch cast stands in so that the ORDER
+    # (broadcast, then re-cast) is what gets tested: attach before the broadcast, as a careless caller would
+    from devit_amd import ops
+    ops.cast_bf16 = lambda src, dst=None: dst.copy_(src)
+    flat.attach_bf16(model)
     ddp.broadcast_parameters(flat)
+    bf16_ok = torch.equal(flat.flat16, flat.flat.to(torch.bfloat16)) and all(
+        torch.equal(m._w16[1].reshape(-1), m.weight.detach().to(torch.bfloat16).reshape(-1)) for m in model if isinstance(m, torch.nn.Linear))
     red = ddp.BucketedGradReducer(flat, bucket_bytes=4096)
     assert len(red.buckets) >= 2
     torch.manual_seed(100 + rank)              # different data per rank
@@ -43,12 +50,21 @@ def _worker(rank, world, port, q):
     for p, g in reversed(list(zip(params, local))):
         p.grad.add_(g)
         red.mark_ready([p])
-    red.finish()
+    order = red.finish()
+    assert order == sorted(order) and len(order) == len(red.buckets)     # buckets leave in flat (= reverse forward) order
+    assert flat.grad_scale == 1.0 / world                                  # sums in the buffer, the mean in the scale
     gathered = [torch.zeros_like(torch.cat([g.reshape(-1) for g in local])) for _ in range(world)]
     dist.all_gather(gathered, torch.cat([g.reshape(-1) for g in local]))
     mean = sum(gathered) / world
-    got = torch.cat([p.grad.reshape(-1) for p in params])
-    ok = torch.allclose(got, mean, rtol=1e-6, atol=1e-7)
+    got = torch.cat([p.grad.reshape(-1) for p in params]) * flat.grad_scale
+    ok = torch.allclose(got, mean, rtol=1e-6, atol=1e-7) and bf16_ok
+    # a parameter reported twice in one backward is a bug in the autograd nodes: refuse it
+    red.mark_ready([params[0]])
+    try:
+        red.mark_ready([params[0]])
+        ok = False
+    except RuntimeError:
+        red.reset()
     w0 = torch.cat([p.detach().reshape(-1) for p in params])
     allw = [torch.zeros_like(w0) for _ in range(world)]
     dist.all_gather(allw, w0)

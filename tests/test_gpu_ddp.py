@@ -1,0 +1,122 @@
+"""The data-parallel exchange on the REAL student (config 4, distill_sub.py:332-334) as far as one GPU allows: a
+recording communicator stands in for RCCL with the world size forced to 2.  Checked: every one of the 155 parameters
+is reported exactly once per backward by the autograd nodes (HeadsFn / EncoderFn / PatchEmbedFn), every bucket's
+all-reduce is launched DURING backward (before finish()) and in flat = reverse-layer order, the exchanged buffer is
+the sum over the (two identical) ranks, and the optimizer's grad_scale turns it back into the mean."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class RecordingComm:
+    """world = 2, every rank holding the same gradient: the all-reduce (SUM) doubles the bucket in place, on the stream it
+    is given -- like RCCL, asynchronously."""
+
+    def __init__(self):
+        self.world, self.calls, self.in_backward = 2, [], False
+
+    def all_reduce(self, view, stream=None):
+        self.calls.append((view.data_ptr(), view.numel(), self.in_backward))
+        with torch.cuda.stream(stream):
+            view.mul_(2.0)
+
+
+def _step(student, teacher, img, soft):
+    from devit_amd import engine
+    out = engine.distill_forward(student, teacher, img, soft, dp_scales=None)
+    out["loss"].backward()
+    return out
+
+
+def test_real_model_reports_every_parameter_once_and_buckets_overlap():
+    import devit_amd
+    from devit_amd import ddp, optim
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    C, B = 25, 4
+    student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.0).to(dev).train()
+    teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
+    for p in teacher.parameters():
+        p.requires_grad_(False)
+    img = torch.randn(B, 3, 224, 224, device=dev)
+    soft = torch.full((B, C), 0.1 / C, device=dev)
+    soft[:, 3] += 0.9
+
+    flat = ddp.FlatParams(student)
+    flat.attach_bf16(student)
+    assert len(flat.params) == 155
+
+    # reference: the local gradient, no exchange
+    flat.zero_grad()
+    _step(student, teacher, img, soft)
+    torch.cuda.synchronize()
+    local = flat.flat_grad.clone()
+    assert float(local.abs().max()) > 0
+
+    comm = RecordingComm()
+    red = ddp.BucketedGradReducer(flat, bucket_bytes=8 << 20, comm=comm).attach(student)   # 87 MB -> ~11 buckets
+    assert red.world == 2 and len(red.buckets) >= 8
+    seen = []
+    inner = red.mark_ready
+    student.grad_ready = lambda params: (seen.extend(flat.index[id(p)] for p in params), inner(params))[1]
+
+    flat.zero_grad()
+    comm.in_backward = True
+    _step(student, teacher, img, soft)
+    comm.in_backward = False
+    launched_in_backward = len(comm.calls)
+    order = red.finish()
+    torch.cuda.synchronize()
+
+    assert sorted(seen) == list(range(155)), "every parameter exactly once"            # (a double report raises already)
+    assert launched_in_backward == len(red.buckets) == len(comm.calls), "all buckets must leave during backward"
+    assert all(flag for _, _, flag in comm.calls)
+    assert order == list(range(len(red.buckets))), "reverse-layer (= flat) order"
+    base = flat.flat_grad.data_ptr()
+    assert [(p - base) // 4 for p, _, _ in comm.calls] == [s for s, _, _, _ in red.buckets]
+    assert sum(n for _, n, _ in comm.calls) == flat.numel
+    # heads' bucket first, the patch embedding's last
+    assert flat.names[0].startswith("head") and flat.names[-1] in ("cls_token", "pos_embed", "dist_token")
+    assert flat.grad_scale == 0.5
+    torch.testing.assert_close(flat.flat_grad, 2.0 * local, rtol=0, atol=0)              # same kernels, same order: exact
+
+    # the optimizer folds 1 / world back in: same update as a single-rank step on the local gradient
+    w0 = flat.flat.clone()
+    opt = optim.FlatAdamW(flat, lr=1e-3, max_norm=1.0)
+    opt.step()
+    torch.cuda.synchronize()
+    w_ddp = flat.flat.clone()
+    flat.flat.copy_(w0)
+    flat.flat_grad.copy_(local)
+    opt2 = optim.FlatAdamW(flat, lr=1e-3, max_norm=1.0)
+    opt2.step()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(w_ddp, flat.flat, rtol=1e-6, atol=1e-9)
+
+
+def test_weight_decay_groups_match_torch_adamw():
+    """timm create_optimizer (distill_sub.py:340): no decay for 1-D tensors, biases and no_weight_decay() names."""
+    import devit_amd
+    from devit_amd import ddp, optim
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    m = devit_amd.create_model("dedeit", num_classes=10).to(dev)
+    skip = optim.no_decay_names(m)
+    assert {"pos_embed", "cls_token", "dist_token", "blocks.0.norm1.weight", "blocks.3.mlp.fc1.bias", "head.bias"} <= skip
+    assert "blocks.0.attn.qkv.weight" not in skip and "patch_embed.proj.weight" not in skip
+    ref = {n: p.detach().clone() for n, p in m.named_parameters()}
+    flat = ddp.FlatParams(m)
+    g = torch.randn_like(flat.flat) * 1e-2
+    flat.flat_grad.copy_(g)
+    opt = optim.FlatAdamW(flat, lr=1e-2, weight_decay=0.05, no_decay=skip)
+    opt.step()
+    torch.cuda.synchronize()
+    params = {n: torch.nn.Parameter(v.clone()) for n, v in ref.items()}
+    topt = torch.optim.AdamW([{"params": [p for n, p in params.items() if n not in skip], "weight_decay": 0.05},
+                              {"params": [p for n, p in params.items() if n in skip], "weight_decay": 0.0}], lr=1e-2)
+    for name, p, o in zip(flat.names, flat.params, flat.offsets):
+        params[name].grad = g[o:o + p.numel()].view_as(p).clone()
+    topt.step()
+    for n, p in m.named_parameters():
+        torch.testing.assert_close(p.detach(), params[n].detach(), rtol=2e-6, atol=2e-8, msg=n)

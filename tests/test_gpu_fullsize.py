@@ -1,7 +1,10 @@
 """Properties at BASELINE.json's FULL sizes (B = 256, N = 198 -> M = 50688 token rows), where a CPU oracle run would take
 minutes: exact integer arithmetic through the bf16 MFMA path (every product and partial sum representable, so the result
 must equal the integer matmul bit for bit), linearity, softmax row sums, LayerNorm statistics, and bit-reproducibility
-of the student / teacher forward.  The bs-8 comparisons with the oracle and the goldens are in test_gpu_model.py."""
+of the student / teacher forward; the BACKWARD kernels at their full grids (attention 1536 workgroups, LayerNorm 50688
+rows) against torch fp32 autograd on image slices; and the whole bs-256 DEKD step in bf16 against the same step on the
+exact-fp32 path (which test_gpu_model.py pins to the reference goldens at 2e-6).  The bs-8 comparisons with the oracle
+and the goldens are in test_gpu_model.py."""
 import pytest
 import torch
 
@@ -117,3 +120,135 @@ def test_forward_bit_reproducible_full_size(dev):
         b1, b2 = t(img), t(img)
     assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1]) and torch.equal(b1, b2)
     assert bool(torch.isfinite(a1[0]).all()) and bool(torch.isfinite(b1).all()) and b1.shape == (B, 25)
+
+
+# ------------------------------------------------------------------------------------------ backward at full size
+def relmax(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("H,with_add", [(6, True), (12, False)])
+def test_attention_backward_full_size(dev, H, with_add):
+    """attn_bwd_kernel on its full grid (B x H = 1536 / 3072 workgroups, one per CU at 152 KB of LDS): dq/dk/dv of three
+    16-image slices (first, middle, last images) against torch fp32 autograd of softmax attention on the same bf16
+    inputs; the relation-loss gradient that the student's middle block adds in is checked on the student shape."""
+    from devit_amd import ops
+    from devit_amd._lib import call, ptr, stream_ptr
+    D = H * 64
+    g = torch.Generator(device=dev).manual_seed(11 + H)
+    qkv = ops.rows_alloc(M, 3 * D, BF16, dev)
+    qkv[:M] = (torch.randn((M, 3 * D), generator=g, device=dev) * 0.8).to(BF16)
+    gate = torch.ones(H, device=dev)
+    gate[1], gate[2] = 0.0, 0.5
+    out = ops.rows_alloc(M, D, BF16, dev)
+    lse = torch.empty((B, H, N), dtype=F32, device=dev)
+    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, stream_ptr())
+    dout = ops.rows_alloc(M, D, BF16, dev)
+    dout[:M] = torch.randn((M, D), generator=g, device=dev).to(BF16)
+    add = None
+    if with_add:
+        add = ops.rows_alloc(M, 3 * D, BF16, dev)
+        add[:M] = (torch.randn((M, 3 * D), generator=g, device=dev) * 0.5).to(BF16)
+    dqkv = ops.rows_alloc(M, 3 * D, BF16, dev)
+    call("devit_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(gate), ptr(add), ptr(dqkv), B, N, H, 64, 0.125,
+         stream_ptr())
+    assert bool(torch.isfinite(dqkv[:M].float()).all())
+    for b0 in (0, 120, B - 16):
+        r0, r1 = b0 * N, (b0 + 16) * N
+        x = qkv[r0:r1].float().requires_grad_(True)
+        v = x.view(16, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        a = ((v[0] @ v[1].transpose(-2, -1)) * 0.125).softmax(-1)
+        o = ((a @ v[2]).transpose(1, 2) * gate.view(1, 1, H, 1)).reshape(16 * N, D)
+        assert relmax(out[r0:r1], o) < 1e-2
+        o.backward(dout[r0:r1].float())
+        ref = x.grad + (add[r0:r1].float() if add is not None else 0)
+        e = relmax(dqkv[r0:r1], ref)
+        assert e < 2e-2, f"images {b0}..{b0 + 16}: dqkv rel-to-max err {e:.3e}"
+
+
+@pytest.mark.parametrize("D", [384, 768])
+def test_layernorm_backward_full_size(dev, D):
+    """ln_bwd_kernel over all 50688 rows (the fused form the blocks use: bf16 dy in, residual gradient added, per-image
+    DropPath scale on the bf16 copy, gamma / beta gradients, column sums of the bf16 copy): dx on three 16-image slices
+    and the four full-length reductions against torch fp32 autograd."""
+    from devit_amd import ops
+    g = torch.Generator(device=dev).manual_seed(21 + D)
+    x = torch.randn((M, D), generator=g, device=dev) * 2.0 + 0.3
+    gm = 1 + 0.1 * torch.randn(D, generator=g, device=dev)
+    bt = 0.1 * torch.randn(D, generator=g, device=dev)
+    y = torch.empty((M, D), dtype=BF16, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, M, D, gm, bt, 1e-6, y_bf16=y, mean=mean, rstd=rstd)
+    dy = torch.randn((M, D), generator=g, device=dev).to(BF16)
+    dres = torch.randn((M, D), generator=g, device=dev)
+    rsc = (torch.arange(B, device=dev) % 7 != 0).float() / 0.9
+    dx = torch.empty((M, D), dtype=F32, device=dev)
+    dxb = torch.empty((M, D), dtype=BF16, device=dev)
+    dg, db, gs = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    ops.layernorm_bwd(dy, False, x, M, D, mean, rstd, gm, dres, dx, dxb, rsc, N, dg, db, gsum=gs)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    ref.backward(dy.float())
+    want = xr.grad + dres
+    for b0 in (0, 120, B - 16):
+        r0, r1 = b0 * N, (b0 + 16) * N
+        assert relmax(dx[r0:r1], want[r0:r1]) < 1e-5
+        assert relmax(dxb[r0:r1], want[r0:r1] * rsc[b0:b0 + 16].repeat_interleave(N)[:, None]) < 2 ** -7
+    assert relmax(dg, gr.grad) < 2e-4 and relmax(db, br.grad) < 2e-4      # 50688-term fp32 sums, different order
+    assert relmax(gs, dxb.float().sum(0)) < 2e-4
+
+
+def test_distill_step_bf16_vs_f32_full_size(dev):
+    """The benchmarked step at BASELINE's size (bs 256, C = 25, DeiT-B -> dedeit), bf16 path against the exact-fp32 path
+    (precision="f32": pinned to the reference goldens at 2e-6 by test_gpu_model.test_f32_path_meets_1e3_bar) on the
+    same weights, inputs and DropPath masks: the five losses, every parameter's gradient norm, gradient slices of every
+    kind of parameter.  This is the only place the bs-256 backward (attention / LayerNorm backward at 1536 workgroups /
+    50688 rows, dGELU dgrad, split-K wgrads with fused bias gradients, relation-loss gradient) is compared with anything."""
+    import devit_amd
+    from devit_amd import engine
+    torch.manual_seed(3)
+    C = 25
+    s = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None).to(dev).train()
+    t = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
+    for p in t.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device=dev).manual_seed(31)
+    img = torch.randn((B, 3, 224, 224), generator=g, device=dev)
+    y1, y2 = torch.randint(0, C, (B,), generator=g, device=dev), torch.randint(0, C, (B,), generator=g, device=dev)
+    oh = lambda y: torch.full((B, C), 0.1 / C, device=dev).scatter_(1, y[:, None], 0.9 + 0.1 / C)
+    soft = 0.7 * oh(y1) + 0.3 * oh(y2)
+    keep = torch.linspace(0, 0.1, 12)
+    dps = []
+    for i in range(12):
+        k = 1.0 - float(keep[i])
+        u = torch.rand((2, B), generator=g, device=dev)
+        sc = torch.floor(k + u) / k
+        dps.append((sc[0].contiguous(), sc[1].contiguous()))
+    res = {}
+    for prec in ("f32", "bf16"):
+        s.precision = t.precision = prec
+        for p in s.parameters():
+            p.grad = None
+        out = engine.distill_forward(s, t, img, soft, gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0, dp_scales=dps)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[prec] = ({k: float(out[k]) for k in ("loss", "cls_loss", "q_loss", "k_loss", "v_loss")},
+                     {n: p.grad.detach().clone() for n, p in s.named_parameters()},
+                     out["logits"][0].detach().clone(), out["teacher_logits"].detach().clone())
+    s.precision = t.precision = "bf16"
+    (l32, g32, lo32, tl32), (l16, g16, lo16, tl16) = res["f32"], res["bf16"]
+    for k in l32:
+        assert abs(l16[k] - l32[k]) < 2e-3 * abs(l32[k]), (k, l16[k], l32[k])
+    assert relmax(lo16, lo32) < 1.5e-2 and relmax(tl16, tl32) < 1.5e-2
+    n32 = torch.stack([g32[n].norm() for n in g32])
+    n16 = torch.stack([g16[n].norm() for n in g32])
+    bad = (n16 - n32).abs() > 1e-2 * n32 + 1e-3 * n32.max()
+    assert not bool(bad.any()), [(n, float(a), float(b)) for n, a, b, f in zip(g32, n16, n32, bad) if f][:8]
+    slices = ["head.weight", "head_dist.bias", "norm.weight", "blocks.11.mlp.fc2.weight", "blocks.11.mlp.fc2.bias",
+              "blocks.7.mlp.fc1.weight", "blocks.7.mlp.fc1.bias", "blocks.5.attn.qkv.weight", "blocks.5.attn.qkv.bias",
+              "blocks.5.attn.proj.weight", "blocks.2.norm1.weight", "blocks.0.norm2.bias", "blocks.0.attn.proj.bias",
+              "patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed", "cls_token", "dist_token"]
+    for n in slices:
+        e = relmax(g16[n], g32[n])
+        assert e < 2e-2, f"{n}: gradient rel-to-max err {e:.3e}"

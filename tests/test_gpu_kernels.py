@@ -410,7 +410,7 @@ def test_adamw_and_sumsq(dev):
         ema_ref = ema_ref * 0.999 + 0.001 * ref_p.detach()
         call("devit_sumsq_f32", ptr(g), n, ptr(gsq), ptr(ws), ws.numel(), stream_ptr())
         dyn = torch.tensor([1e-3, 1 - 0.9 ** step, 1 - 0.999 ** step], device=dev)
-        call("devit_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), ptr(p16), ptr(gsq), ptr(dyn), n, 0.9, 0.999,
+        call("devit_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), ptr(p16), None, ptr(gsq), ptr(dyn), n, 0.9, 0.999,
              1e-8, 0.05, 1.0, 0.999, 1.0, stream_ptr())
     assert abs(float(gsq) - float((g * g).sum())) < 1e-4 * float((g * g).sum())
     assert relerr(p, ref_p.detach()) < 1e-5 and relerr(ema, ema_ref) < 1e-5

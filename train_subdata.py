@@ -28,11 +28,13 @@ def get_args_parser():
     p.add_argument('--distillation-type', default='none', choices=['none', 'soft', 'hard'], type=str)
     p.add_argument('--epochs', default=5, type=int)
     p.add_argument('--weight-decay', type=float, default=0)
+    p.add_argument('--no-aug', action='store_true', help='not use aug')            # train_subdata.py:112
     return p
 
 
 def main(args):
     utils.init_distributed_mode(args)
+    ds.check_supported(args)
     device = torch.device(args.device)
     seed = args.seed + utils.get_rank()
     torch.manual_seed(seed)
@@ -68,13 +70,15 @@ def main(args):
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
 
-    flat = ddp.FlatParams(model).attach_bf16(model)
-    ddp.broadcast_parameters(flat)
+    flat = ddp.FlatParams(model)
+    ddp.broadcast_parameters(flat)          # ranks are seeded seed + rank: rank 0's weights first, then the bf16 copies
+    flat.attach_bf16(model)
     reducer = ddp.BucketedGradReducer(flat).attach(model)
     args.lr = args.lr * args.batch_size * utils.get_world_size() / 512.0             # train_subdata.py:404-405
     optimizer = optim.FlatAdamW(flat, lr=args.lr, eps=args.opt_eps, betas=tuple(args.opt_betas or (0.9, 0.999)),
                                 weight_decay=args.weight_decay, max_norm=args.clip_grad,
-                                ema_decay=args.model_ema_decay if args.model_ema else None)
+                                ema_decay=args.model_ema_decay if args.model_ema else None,
+                                no_decay=optim.no_decay_names(model))
     loss_scaler, lr_scheduler = ds.StepRunner(reducer), ds.CosineEpochs(optimizer, args)
     if mixup_fn is not None:                                                         # :409-416
         base = losses.SoftTargetCrossEntropy()
