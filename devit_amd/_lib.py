@@ -28,6 +28,33 @@ class Operand(C.Structure):
                 ("row_skip", C.c_int), ("batch_stride", C.c_longlong)]
 
 
+ACT_LN1, ACT_MEAN1, ACT_RSTD1, ACT_QKV, ACT_ATTN_O, ACT_LSE, ACT_X1, ACT_ATT, ACT_LN2, ACT_MEAN2, ACT_RSTD2, ACT_H, ACT_H_PRE, \
+    ACT_X2, ACT_COUNT = range(15)
+BLK_SAVE, BLK_QKV_PAD, BLK_ATT = 1, 2, 4
+BWD_DH_PRE, BWD_DLN2, BWD_DX1, BWD_G1, BWD_DATTN, BWD_DQKV, BWD_DLN1, BWD_LNWS, BWD_COUNT = range(9)
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("n1w", "n1b", "qkv_b", "proj_b", "n2w", "n2b", "fc1_b", "fc2_b", "qkv_w16",
+                                          "proj_w16", "fc1_w16", "fc2_w16", "head_gate", "neuron_gate")] + \
+               [("num_heads", C.c_int), ("attn_width", C.c_int), ("hidden", C.c_int)]
+
+
+class BlockWgrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("n1w", "n1b", "qkv_w", "qkv_b", "proj_w", "proj_b", "n2w", "n2b", "fc1_w",
+                                          "fc1_b", "fc2_w", "fc2_b")]
+
+
+class BlockActs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("buf", C.c_void_p * 14), ("dp1", C.c_void_p), ("dp2", C.c_void_p), ("flags", C.c_int)]
+
+
+class BlockBwdIO(C.Structure):
+    _fields_ = [("dx", C.c_void_p), ("g2", C.c_void_p), ("dx_in", C.c_void_p), ("g_prev", C.c_void_p),
+                ("prev_dp2", C.c_void_p), ("prev_fc2_b_grad", C.c_void_p), ("g2_bias_done", C.c_int),
+                ("dqkv_add", C.c_void_p), ("ws", C.c_void_p * 8), ("lnws_bytes", C.c_size_t)]
+
+
 class DevitError(RuntimeError):
     pass
 
@@ -43,6 +70,11 @@ SIGNATURES = {
     "devit_layernorm_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "devit_layernorm_bwd_workspace": (_Z, [_I, _I]),
     "devit_layernorm_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
+    "devit_block_acts_sizes": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(C.c_size_t)]),
+    "devit_block_bwd_sizes": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_size_t)]),
+    "devit_encoder_fwd": (_I, [_I, C.POINTER(BlockWeights), C.POINTER(BlockActs), _I, _I, _I, _F, _P]),
+    "devit_block_bwd": (_I, [C.POINTER(BlockWeights), C.POINTER(BlockActs), C.POINTER(BlockWgrads), C.POINTER(BlockBwdIO),
+                             _I, _I, _I, _F, _P]),
     "devit_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "devit_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "devit_im2row_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

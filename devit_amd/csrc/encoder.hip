@@ -1,0 +1,237 @@
+// Whole encoder blocks per host call (devit_encoder_fwd / devit_block_bwd): the block's kernels are enqueued here, in C++,
+// through the same single-kernel entry points the granular path uses -- identical kernels, arguments and order, so the
+// two paths agree bit for bit (tests/test_gpu_kernels.py::test_block_calls_match_granular_path).  Host code only.
+#include "devit_common.h"
+
+namespace {
+
+inline int pad_rows(int m) { return (m + 255) / 256 * 256; }
+inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+// split-K factor of a weight-gradient GEMM: one round of resident 128x128 workgroups (two per CU), see ops.split_k_for
+inline int split_k_for(int out_rows, int out_cols, int ksteps) {
+  const int tiles = (out_rows / 128) * (out_cols / 128);
+  int s = 512 / (tiles > 0 ? tiles : 1);
+  if (s > ksteps) s = ksteps;
+  return s < 1 ? 1 : s;
+}
+
+struct Ctx {
+  int M, Mp, B, N, D;
+  float eps;
+  void* stream;
+};
+
+int zero_pad(const Ctx& c, void* buf, int cols, size_t elem, int extra_rows = 0) {
+  if (!buf) return DEVIT_OK;
+  const int rows = c.Mp + extra_rows - c.M;
+  if (rows <= 0) return DEVIT_OK;
+  hipError_t e = hipMemsetAsync((char*)buf + (size_t)c.M * cols * elem, 0, (size_t)rows * cols * elem, (hipStream_t)c.stream);
+  DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  return DEVIT_OK;
+}
+
+devit_epilogue make_ep(int kind, void* out, int ldc, int m_valid) {
+  devit_epilogue ep = {};
+  ep.kind = kind;
+  ep.out = out;
+  ep.ldc = ldc;
+  ep.m_valid = m_valid;
+  return ep;
+}
+
+// out[M][Nout] = x[Mp][K] @ w[Nout][K]^T (+ epilogue)
+int linear_fwd(const Ctx& c, const void* x, const void* w, int Nout, int K, devit_epilogue ep) {
+  devit_operand A = {x, K, 0, 0, 0, 0}, Bo = {w, K, 0, 0, 0, 0};
+  return devit_gemm_bf16(&A, &Bo, c.Mp, Nout, K, 1, 1, &ep, c.stream);
+}
+// out[M][K] = dy[Mp][Nw] @ w[Nw][K]   (w read k-major)
+int linear_dgrad(const Ctx& c, const void* dy, const void* w, int Nw, int K, devit_epilogue ep) {
+  devit_operand A = {dy, Nw, 0, 0, 0, 0}, Bo = {w, K, 1, 0, 0, 0};
+  return devit_gemm_bf16(&A, &Bo, c.Mp, K, Nw, 1, 1, &ep, c.stream);
+}
+// w_grad[Nw][K] += dy[Mp][Nw]^T @ x[Mp][K]; b_grad[Nw] += column sums of dy (same launch)
+int linear_wgrad(const Ctx& c, const void* dy, const void* x, float* w_grad, float* b_grad, int Nw, int K) {
+  devit_operand A = {dy, Nw, 1, 0, 0, 0}, Bo = {x, K, 1, 0, 0, 0};
+  devit_epilogue ep = make_ep(DEVIT_EPI_ATOMIC_F32, w_grad, K, 0);
+  ep.aux = b_grad;
+  return devit_gemm_bf16(&A, &Bo, Nw, K, c.Mp, 1, split_k_for(Nw, K, c.Mp / 64), &ep, c.stream);
+}
+
+#define TRY(x)                 \
+  do {                         \
+    int rc__ = (x);            \
+    if (rc__ != DEVIT_OK) return rc__; \
+  } while (0)
+
+int check_dims(int B, int N, int D, int Da, int Hd) {
+  DEVIT_CHECK(B > 0 && N > 0 && N <= 208 && D > 0 && D % 128 == 0 && Da > 0 && Da % 128 == 0 && Hd > 0 && Hd % 128 == 0,
+              DEVIT_ERR_SHAPE, "block: B=%d N=%d D=%d attn_width=%d hidden=%d not supported", B, N, D, Da, Hd);
+  return DEVIT_OK;
+}
+
+int block_fwd(const Ctx& c, const devit_block_weights& w, const devit_block_acts& a) {
+  const int D = c.D, Da = w.attn_width, Hd = w.hidden, H = w.num_heads;
+  TRY(check_dims(c.B, c.N, D, Da, Hd));
+  DEVIT_CHECK(H > 0 && Da == H * 64, DEVIT_ERR_SHAPE, "block: attn_width %d != heads %d * 64", Da, H);
+  const bool save = a.flags & DEVIT_BLK_SAVE;
+  void* const* b = a.buf;
+  DEVIT_CHECK(a.x && b[DEVIT_ACT_LN1] && b[DEVIT_ACT_QKV] && b[DEVIT_ACT_ATTN_O] && b[DEVIT_ACT_X1] && b[DEVIT_ACT_LN2] &&
+                  b[DEVIT_ACT_H] && b[DEVIT_ACT_X2],
+              DEVIT_ERR_ARG, "devit_encoder_fwd: null activation buffer");
+  DEVIT_CHECK(!save || (b[DEVIT_ACT_MEAN1] && b[DEVIT_ACT_RSTD1] && b[DEVIT_ACT_LSE] && b[DEVIT_ACT_MEAN2] &&
+                        b[DEVIT_ACT_RSTD2] && b[DEVIT_ACT_H_PRE]),
+              DEVIT_ERR_ARG, "devit_encoder_fwd: DEVIT_BLK_SAVE needs the mean/rstd/lse/h_pre buffers");
+  DEVIT_CHECK(!(a.flags & DEVIT_BLK_ATT) || b[DEVIT_ACT_ATT], DEVIT_ERR_ARG, "devit_encoder_fwd: DEVIT_BLK_ATT needs att");
+  TRY(zero_pad(c, b[DEVIT_ACT_LN1], D, 2));
+  TRY(zero_pad(c, b[DEVIT_ACT_QKV], 3 * Da, 2, (a.flags & DEVIT_BLK_QKV_PAD) ? 128 : 0));
+  TRY(zero_pad(c, b[DEVIT_ACT_ATTN_O], Da, 2));
+  TRY(zero_pad(c, b[DEVIT_ACT_LN2], D, 2));
+  TRY(zero_pad(c, b[DEVIT_ACT_H], Hd, 2));
+  if (save) TRY(zero_pad(c, b[DEVIT_ACT_H_PRE], Hd, 2));
+  // ---- x1 = x + dp1 * proj(gate * attn(qkv(ln1(x))))
+  TRY(devit_layernorm_fwd(a.x, c.M, D, 0, 0, w.n1w, w.n1b, c.eps, b[DEVIT_ACT_LN1], nullptr,
+                          save ? (float*)b[DEVIT_ACT_MEAN1] : nullptr, save ? (float*)b[DEVIT_ACT_RSTD1] : nullptr, c.stream));
+  {
+    devit_epilogue ep = make_ep(DEVIT_EPI_STORE_BF16, b[DEVIT_ACT_QKV], 3 * Da, c.M);
+    ep.bias = w.qkv_b;
+    TRY(linear_fwd(c, b[DEVIT_ACT_LN1], w.qkv_w16, 3 * Da, D, ep));
+  }
+  TRY(devit_attn_fwd(b[DEVIT_ACT_QKV], b[DEVIT_ACT_ATTN_O], save ? (float*)b[DEVIT_ACT_LSE] : nullptr, w.head_gate, c.B, c.N, H,
+                     64, 0.125f, c.stream));
+  {
+    devit_epilogue ep = make_ep(DEVIT_EPI_RESIDUAL_F32, b[DEVIT_ACT_X1], D, c.M);
+    ep.bias = w.proj_b;
+    ep.res = a.x;
+    ep.rowscale = a.dp1;
+    ep.rows_per_scale = c.N;
+    ep.aux = (a.flags & DEVIT_BLK_ATT) ? b[DEVIT_ACT_ATT] : nullptr;
+    TRY(linear_fwd(c, b[DEVIT_ACT_ATTN_O], w.proj_w16, D, Da, ep));
+  }
+  // ---- x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2(x1))))
+  TRY(devit_layernorm_fwd((const float*)b[DEVIT_ACT_X1], c.M, D, 0, 0, w.n2w, w.n2b, c.eps, b[DEVIT_ACT_LN2], nullptr,
+                          save ? (float*)b[DEVIT_ACT_MEAN2] : nullptr, save ? (float*)b[DEVIT_ACT_RSTD2] : nullptr, c.stream));
+  {
+    devit_epilogue ep = make_ep(DEVIT_EPI_GELU_BF16, b[DEVIT_ACT_H], Hd, c.M);
+    ep.bias = w.fc1_b;
+    ep.colscale = w.neuron_gate;
+    ep.aux = save ? b[DEVIT_ACT_H_PRE] : nullptr;
+    TRY(linear_fwd(c, b[DEVIT_ACT_LN2], w.fc1_w16, Hd, D, ep));
+  }
+  {
+    devit_epilogue ep = make_ep(DEVIT_EPI_RESIDUAL_F32, b[DEVIT_ACT_X2], D, c.M);
+    ep.bias = w.fc2_b;
+    ep.res = (const float*)b[DEVIT_ACT_X1];
+    ep.rowscale = a.dp2;
+    ep.rows_per_scale = c.N;
+    TRY(linear_fwd(c, b[DEVIT_ACT_H], w.fc2_w16, D, Hd, ep));
+  }
+  return DEVIT_OK;
+}
+
+}  // namespace
+
+extern "C" int devit_block_acts_sizes(int B, int N, int D, int Da, int Hd, int flags, size_t* sizes) {
+  DEVIT_CHECK(sizes != nullptr, DEVIT_ERR_ARG, "devit_block_acts_sizes: null");
+  TRY(check_dims(B, N, D, Da, Hd));
+  const size_t M = (size_t)B * N, Mp = pad_rows((int)M);
+  const bool save = flags & DEVIT_BLK_SAVE;
+  sizes[DEVIT_ACT_LN1] = Mp * D * 2;
+  sizes[DEVIT_ACT_MEAN1] = sizes[DEVIT_ACT_RSTD1] = sizes[DEVIT_ACT_MEAN2] = sizes[DEVIT_ACT_RSTD2] = save ? M * 4 : 0;
+  sizes[DEVIT_ACT_QKV] = (Mp + ((flags & DEVIT_BLK_QKV_PAD) ? 128 : 0)) * 3 * (size_t)Da * 2;
+  sizes[DEVIT_ACT_ATTN_O] = Mp * Da * 2;
+  sizes[DEVIT_ACT_LSE] = save ? (size_t)B * (Da / 64) * N * 4 : 0;
+  sizes[DEVIT_ACT_X1] = M * D * 4;
+  sizes[DEVIT_ACT_ATT] = (flags & DEVIT_BLK_ATT) ? M * D * 2 : 0;
+  sizes[DEVIT_ACT_LN2] = Mp * D * 2;
+  sizes[DEVIT_ACT_H] = Mp * Hd * 2;
+  sizes[DEVIT_ACT_H_PRE] = save ? Mp * Hd * 2 : 0;
+  sizes[DEVIT_ACT_X2] = M * D * 4;
+  for (int i = 0; i < DEVIT_ACT_COUNT; ++i) sizes[i] = align256(sizes[i]);
+  return DEVIT_OK;
+}
+
+extern "C" int devit_block_bwd_sizes(int B, int N, int D, int Da, int Hd, size_t* sizes) {
+  DEVIT_CHECK(sizes != nullptr, DEVIT_ERR_ARG, "devit_block_bwd_sizes: null");
+  TRY(check_dims(B, N, D, Da, Hd));
+  DEVIT_CHECK(Da == D, DEVIT_ERR_SHAPE, "devit_block_bwd: compacted blocks (attn_width != D) are inference-only");
+  const size_t M = (size_t)B * N, Mp = pad_rows((int)M);
+  sizes[DEVIT_BWD_DH_PRE] = Mp * Hd * 2;
+  sizes[DEVIT_BWD_DLN2] = sizes[DEVIT_BWD_G1] = sizes[DEVIT_BWD_DATTN] = sizes[DEVIT_BWD_DLN1] = Mp * D * 2;
+  sizes[DEVIT_BWD_DX1] = M * D * 4;
+  sizes[DEVIT_BWD_DQKV] = Mp * 3 * (size_t)D * 2;
+  sizes[DEVIT_BWD_LNWS] = devit_layernorm_bwd_workspace((int)M, D);
+  for (int i = 0; i < DEVIT_BWD_COUNT; ++i) sizes[i] = align256(sizes[i]);
+  return DEVIT_OK;
+}
+
+extern "C" int devit_encoder_fwd(int nblocks, const devit_block_weights* w, const devit_block_acts* acts, int B, int N, int D,
+                                 float eps, void* stream) {
+  DEVIT_CHECK(nblocks > 0 && w && acts, DEVIT_ERR_ARG, "devit_encoder_fwd: bad argument");
+  Ctx c{B * N, pad_rows(B * N), B, N, D, eps, stream};
+  for (int i = 0; i < nblocks; ++i) {
+    DEVIT_CHECK(i == 0 || acts[i].x == (const float*)acts[i - 1].buf[DEVIT_ACT_X2], DEVIT_ERR_ARG,
+                "devit_encoder_fwd: block %d does not read block %d's output", i, i - 1);
+    TRY(block_fwd(c, w[i], acts[i]));
+  }
+  return DEVIT_OK;
+}
+
+extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_acts* ap, const devit_block_wgrads* gp,
+                               const devit_block_bwd_io* io, int B, int N, int D, float eps, void* stream) {
+  DEVIT_CHECK(wp && ap && gp && io, DEVIT_ERR_ARG, "devit_block_bwd: null argument");
+  const devit_block_weights& w = *wp;
+  const devit_block_acts& a = *ap;
+  const devit_block_wgrads& g = *gp;
+  const int Hd = w.hidden, H = w.num_heads;
+  TRY(check_dims(B, N, D, w.attn_width, Hd));
+  DEVIT_CHECK(w.attn_width == D && H * 64 == D, DEVIT_ERR_SHAPE, "devit_block_bwd: compacted blocks are inference-only");
+  DEVIT_CHECK(a.flags & DEVIT_BLK_SAVE, DEVIT_ERR_ARG, "devit_block_bwd: the forward ran without DEVIT_BLK_SAVE");
+  DEVIT_CHECK(io->dx && io->g2 && io->dx_in, DEVIT_ERR_ARG, "devit_block_bwd: dx / g2 / dx_in");
+  for (int i = 0; i < DEVIT_BWD_COUNT; ++i) DEVIT_CHECK(io->ws[i], DEVIT_ERR_ARG, "devit_block_bwd: workspace %d is null", i);
+  DEVIT_CHECK(g.n1w && g.n1b && g.qkv_w && g.qkv_b && g.proj_w && g.proj_b && g.n2w && g.n2b && g.fc1_w && g.fc1_b &&
+                  g.fc2_w && g.fc2_b, DEVIT_ERR_ARG, "devit_block_bwd: null gradient accumulator");
+  Ctx c{B * N, pad_rows(B * N), B, N, D, eps, stream};
+  void* const* b = a.buf;
+  void* dh_pre = io->ws[DEVIT_BWD_DH_PRE];
+  void* dln2 = io->ws[DEVIT_BWD_DLN2];
+  float* dx1 = (float*)io->ws[DEVIT_BWD_DX1];
+  void* g1 = io->ws[DEVIT_BWD_G1];
+  void* dattn = io->ws[DEVIT_BWD_DATTN];
+  void* dqkv = io->ws[DEVIT_BWD_DQKV];
+  void* dln1 = io->ws[DEVIT_BWD_DLN1];
+  TRY(zero_pad(c, dh_pre, Hd, 2));
+  TRY(zero_pad(c, dln2, D, 2));
+  TRY(zero_pad(c, g1, D, 2));
+  TRY(zero_pad(c, dattn, D, 2));
+  TRY(zero_pad(c, dqkv, 3 * D, 2));
+  TRY(zero_pad(c, dln1, D, 2));
+  TRY(zero_pad(c, io->g_prev, D, 2));
+  // ---- MLP branch: x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2))).  The weight gradient that only needs g2 first, then
+  // dh_pre's producer and its consumers back to back (dh_pre is 156 MB at B = 256: keep it in the Infinity Cache)
+  TRY(linear_wgrad(c, io->g2, b[DEVIT_ACT_H], g.fc2_w, io->g2_bias_done ? nullptr : g.fc2_b, D, Hd));
+  {
+    devit_epilogue ep = make_ep(DEVIT_EPI_DGELU_BF16, dh_pre, Hd, c.M);
+    ep.colscale = w.neuron_gate;
+    ep.aux_in = b[DEVIT_ACT_H_PRE];
+    TRY(linear_dgrad(c, io->g2, w.fc2_w16, D, Hd, ep));
+  }
+  TRY(linear_dgrad(c, dh_pre, w.fc1_w16, Hd, D, make_ep(DEVIT_EPI_STORE_BF16, dln2, D, c.M)));
+  TRY(linear_wgrad(c, dh_pre, b[DEVIT_ACT_LN2], g.fc1_w, g.fc1_b, Hd, D));
+  // LN2 backward: dx1 = dx + LN'(dln2); g1 = bf16(dp1 * dx1); its column sums = the proj bias gradient
+  TRY(devit_layernorm_bwd(dln2, 0, (const float*)b[DEVIT_ACT_X1], c.M, D, 0, 0, (const float*)b[DEVIT_ACT_MEAN2],
+                          (const float*)b[DEVIT_ACT_RSTD2], w.n2w, io->dx, dx1, g1, a.dp1, N, g.n2w, g.n2b, g.proj_b, 1,
+                          io->ws[DEVIT_BWD_LNWS], io->lnws_bytes, stream));
+  // ---- attention branch: x1 = x + dp1 * proj(gate * attn(qkv(ln1)))
+  TRY(linear_dgrad(c, g1, w.proj_w16, D, D, make_ep(DEVIT_EPI_STORE_BF16, dattn, D, c.M)));
+  TRY(linear_wgrad(c, g1, b[DEVIT_ACT_ATTN_O], g.proj_w, nullptr, D, D));
+  TRY(devit_attn_bwd(b[DEVIT_ACT_QKV], b[DEVIT_ACT_ATTN_O], dattn, (const float*)b[DEVIT_ACT_LSE], w.head_gate, io->dqkv_add,
+                     dqkv, B, N, H, 64, 0.125f, stream));
+  TRY(linear_dgrad(c, dqkv, w.qkv_w16, 3 * D, D, make_ep(DEVIT_EPI_STORE_BF16, dln1, D, c.M)));
+  TRY(linear_wgrad(c, dqkv, b[DEVIT_ACT_LN1], g.qkv_w, g.qkv_b, 3 * D, D));
+  // LN1 backward: dx_in = dx1 + LN'(dln1); g_prev = bf16(prev_dp2 * dx_in) (+ the block below's fc2 bias gradient)
+  TRY(devit_layernorm_bwd(dln1, 0, a.x, c.M, D, 0, 0, (const float*)b[DEVIT_ACT_MEAN1], (const float*)b[DEVIT_ACT_RSTD1],
+                          w.n1w, dx1, io->dx_in, io->g_prev, io->prev_dp2, N, g.n1w, g.n1b,
+                          io->g_prev ? io->prev_fc2_b_grad : nullptr, 1, io->ws[DEVIT_BWD_LNWS], io->lnws_bytes, stream));
+  return DEVIT_OK;
+}

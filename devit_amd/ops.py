@@ -314,6 +314,165 @@ def scale_cast(dx, rowscale, N):
     return g
 
 
+# ----------------------------------------------------------------------------------------------
+# composite path: whole blocks per ctypes call (devit_encoder_fwd / devit_block_bwd, csrc/encoder.hip).
+# Same kernels, arguments and order as _block_forward / _block_backward above (which stay as the granular path that
+# bench.py's per-kernel instrumentation and the rare extra-gradient cases use); one arena per encoder call instead of
+# ~15 torch allocations per block.  COMPOSITE = False forces the granular path (A/B tests).
+# ----------------------------------------------------------------------------------------------
+COMPOSITE = os.environ.get("DEVIT_COMPOSITE", "1") == "1"
+_sizes_cache = {}
+_ACT_DT = {L.ACT_LN1: BF16, L.ACT_QKV: BF16, L.ACT_ATTN_O: BF16, L.ACT_ATT: BF16, L.ACT_LN2: BF16, L.ACT_H: BF16,
+           L.ACT_H_PRE: BF16}
+
+
+def _act_sizes(B, N, D, Da, Hd, flags):
+    key = ("a", B, N, D, Da, Hd, flags)
+    v = _sizes_cache.get(key)
+    if v is None:
+        sz = (C.c_size_t * L.ACT_COUNT)()
+        call("devit_block_acts_sizes", B, N, D, Da, Hd, flags, sz)
+        offs, off = [], 0
+        for n in sz:
+            offs.append(off)
+            off += n
+        v = _sizes_cache[key] = (list(sz), offs, off)
+    return v
+
+
+def _bwd_sizes(B, N, D, Hd):
+    key = ("b", B, N, D, Hd)
+    v = _sizes_cache.get(key)
+    if v is None:
+        sz = (C.c_size_t * L.BWD_COUNT)()
+        call("devit_block_bwd_sizes", B, N, D, D, Hd, sz)
+        offs, off = [], 0
+        for n in sz:
+            offs.append(off)
+            off += n
+        v = _sizes_cache[key] = (list(sz), offs, off)
+    return v
+
+
+def _weights_struct(bp):
+    w = L.BlockWeights()
+    w.n1w, w.n1b, w.qkv_b, w.proj_b = bp.n1w.data_ptr(), bp.n1b.data_ptr(), bp.qkv_b.data_ptr(), bp.proj_b.data_ptr()
+    w.n2w, w.n2b, w.fc1_b, w.fc2_b = bp.n2w.data_ptr(), bp.n2b.data_ptr(), bp.fc1_b.data_ptr(), bp.fc2_b.data_ptr()
+    w.qkv_w16, w.proj_w16 = bp.qkv_w16.data_ptr(), bp.proj_w16.data_ptr()
+    w.fc1_w16, w.fc2_w16 = bp.fc1_w16.data_ptr(), bp.fc2_w16.data_ptr()
+    w.head_gate, w.neuron_gate = _p(bp.head_gate), _p(bp.neuron_gate)
+    w.num_heads, w.attn_width, w.hidden = bp.num_heads, bp.qkv_w16.shape[0] // 3, bp.fc1_w16.shape[0]
+    return w
+
+
+class _EncoderRun:
+    """What one composite forward leaves behind for backward: the ctypes argument arrays and the arena they point into."""
+    __slots__ = ("weights", "acts", "arena", "x", "dims", "views", "dps")
+
+
+def _encoder_forward_composite(x, cfg, need_grad):
+    B, N, D = x.shape
+    M, dev, nb = B * N, x.device, len(cfg.blocks)
+    mp = pad_rows(M)
+    weights = (L.BlockWeights * nb)()
+    acts = (L.BlockActs * nb)()
+    layouts, total = [], 0
+    for i, bp in enumerate(cfg.blocks):
+        weights[i] = _weights_struct(bp)
+        pad = bool(cfg.want_qkv) and (cfg.qkv_pad_layers is None or i in cfg.qkv_pad_layers)
+        flags = (L.BLK_SAVE if need_grad else 0) | (L.BLK_QKV_PAD if pad else 0) | (L.BLK_ATT if cfg.want_att else 0)
+        sz, offs, tot = _act_sizes(B, N, D, weights[i].attn_width, weights[i].hidden, flags)
+        layouts.append((flags, sz, offs, total))
+        total += tot
+    arena = torch.empty(total, dtype=torch.uint8, device=dev)
+    base = arena.data_ptr()
+    run = _EncoderRun()
+    run.weights, run.acts, run.arena, run.x, run.dims, run.dps = weights, acts, arena, x, (B, N, D), cfg.dp_scales
+    views = []
+    x_ptr = x.data_ptr()
+    for i, bp in enumerate(cfg.blocks):
+        flags, sz, offs, off0 = layouts[i]
+        a = acts[i]
+        a.x = x_ptr
+        for j in range(L.ACT_COUNT):
+            a.buf[j] = base + off0 + offs[j] if sz[j] else None
+        dp = cfg.dp_scales[i] if cfg.dp_scales is not None else None
+        a.dp1, a.dp2 = (_p(dp[0]), _p(dp[1])) if dp is not None else (None, None)
+        a.flags = flags
+        x_ptr = a.buf[L.ACT_X2]
+        Da, Hd = weights[i].attn_width, weights[i].hidden
+
+        def view(j, rows, cols, dt, off0=off0, offs=offs):
+            o = off0 + offs[j]
+            return arena[o:o + rows * cols * dt.itemsize].view(dt).view(rows, cols)
+        qkv_rows = mp + (128 if flags & L.BLK_QKV_PAD else 0)
+        v = dict(qkv=view(L.ACT_QKV, qkv_rows, 3 * Da, BF16), x2=view(L.ACT_X2, M, D, F32).view(B, N, D),
+                 att=view(L.ACT_ATT, M, D, BF16) if cfg.want_att else None)
+        views.append(v)
+        if bp.module is not None:  # shrink contract (core/imp_rank.py:31,108): post-mask values
+            bp.module.mlp.neuron_output = view(L.ACT_H, mp, Hd, BF16)[:M].view(B, N, Hd)
+            bp.module.attn.head_output = view(L.ACT_ATTN_O, mp, Da, BF16)[:M].view(B, N, bp.num_heads, Da // bp.num_heads)
+    run.views = views
+    call("devit_encoder_fwd", nb, weights, acts, B, N, D, cfg.eps, stream_ptr())
+    return run
+
+
+def _wgrads_struct(bp):
+    g = L.BlockWgrads()
+    g.n1w, g.n1b, g.qkv_w, g.qkv_b = (grad_buf(p).data_ptr() for p in (bp.n1w, bp.n1b, bp.qkv_w, bp.qkv_b))
+    g.proj_w, g.proj_b, g.n2w, g.n2b = (grad_buf(p).data_ptr() for p in (bp.proj_w, bp.proj_b, bp.n2w, bp.n2b))
+    g.fc1_w, g.fc1_b, g.fc2_w, g.fc2_b = (grad_buf(p).data_ptr() for p in (bp.fc1_w, bp.fc1_b, bp.fc2_w, bp.fc2_b))
+    return g
+
+
+def _encoder_backward_composite(run, cfg, dx, dqkvs):
+    """dx: fp32 [B,N,D] contiguous gradient of the encoder output.  Returns the gradient of the encoder input."""
+    B, N, D = run.dims
+    M, dev, nb = B * N, dx.device, len(cfg.blocks)
+    mp = pad_rows(M)
+    Hd = run.weights[0].hidden
+    sz, offs, tot = _bwd_sizes(B, N, D, Hd)
+    # transient buffers shared by all blocks + two fp32 dx and two bf16 g buffers that alternate
+    dxb, gb = M * D * 4, mp * D * 2
+    ws = torch.empty(tot + 2 * dxb + 2 * gb, dtype=torch.uint8, device=dev)
+    base = ws.data_ptr()
+    dx_ptrs = [base + tot, base + tot + dxb]
+    g_ptrs = [base + tot + 2 * dxb, base + tot + 2 * dxb + gb]
+    call("devit_scale_cast_bf16", ptr(dx), C.c_void_p(g_ptrs[0]), ptr(run.dps[nb - 1][1]) if run.dps is not None and run.dps[nb - 1] is not None else None,
+         N, M, D, stream_ptr())
+    if mp > M:
+        ws[tot + 2 * dxb + M * D * 2: tot + 2 * dxb + gb].zero_()
+    io = L.BlockBwdIO()
+    for j in range(L.BWD_COUNT):
+        io.ws[j] = base + offs[j]
+    io.lnws_bytes = sz[L.BWD_LNWS]
+    cur_dx, cur_g, g_bias_done = dx.data_ptr(), 0, 0
+    st = stream_ptr()
+    for i in range(nb - 1, -1, -1):
+        bp = cfg.blocks[i]
+        if run.weights[i].hidden != Hd:
+            raise L.DevitError("composite backward: blocks of different hidden width")
+        dq = dqkvs[i] if dqkvs else None
+        if dq is not None:
+            dq = dq.contiguous()
+        out_slot = (nb - 1 - i) & 1
+        io.dx, io.g2, io.dx_in = cur_dx, g_ptrs[cur_g], dx_ptrs[out_slot]
+        prev = cfg.blocks[i - 1] if i > 0 else None
+        io.g_prev = g_ptrs[cur_g ^ 1] if prev is not None else None
+        pdp = run.dps[i - 1] if (prev is not None and run.dps is not None) else None
+        io.prev_dp2 = _p(pdp[1]) if pdp is not None else None
+        io.prev_fc2_b_grad = grad_buf(prev.fc2_b).data_ptr() if prev is not None else None
+        io.g2_bias_done = g_bias_done
+        io.dqkv_add = _p(dq)
+        wg = _wgrads_struct(bp)
+        call("devit_block_bwd", C.byref(run.weights[i]), C.byref(run.acts[i]), C.byref(wg), C.byref(io), B, N, D, cfg.eps, st)
+        cur_dx, cur_g, g_bias_done = dx_ptrs[out_slot], cur_g ^ 1, 1 if prev is not None else 0
+        if cfg.grad_ready is not None:
+            cfg.grad_ready(bp.all_params())
+    o = tot + (0 if cur_dx == dx_ptrs[0] else dxb)
+    return ws[o:o + dxb].view(F32).view(B, N, D)
+
+
 class EncoderFn(torch.autograd.Function):
     """x -> blocks[0..n) -> (x_out, [qkv_i bf16 packed ...], [att_i ...], [enc_i ...])."""
 
@@ -325,6 +484,18 @@ class EncoderFn(torch.autograd.Function):
         if need_grad and any(getattr(bp, "compacted", False) for bp in cfg.blocks):
             raise L.DevitError("a compacted model (devit_amd.shrink.compact) is inference-only: run it under "
                                "torch.no_grad() or call shrink.uncompact(model) before training")
+        ctx.run = None
+        if COMPOSITE and PROFILE is None and PROFILE_HBM is None:
+            run = _encoder_forward_composite(x, cfg, need_grad)
+            nb = len(cfg.blocks)
+            qkvs = [v["qkv"] for v in run.views] if cfg.want_qkv else []
+            atts = [v["att"] for v in run.views] if cfg.want_att else []
+            encs = [run.views[i]["x2"].clone() if i == nb - 1 else run.views[i]["x2"] for i in range(nb)] if cfg.want_enc else []
+            ctx.cfg, ctx.saved, ctx.need_grad = cfg, None, need_grad
+            ctx.run = run if need_grad else None
+            ctx.counts = (len(qkvs), len(atts), len(encs))
+            ctx.set_materialize_grads(False)
+            return (run.views[-1]["x2"],) + tuple(qkvs) + tuple(atts) + tuple(encs)
         saved, qkvs, atts, encs = [], [], [], []
         for i, bp in enumerate(cfg.blocks):
             dp = cfg.dp_scales[i] if cfg.dp_scales is not None else None
@@ -352,6 +523,17 @@ class EncoderFn(torch.autograd.Function):
         nq, na, ne = ctx.counts
         dqkvs, datts, dencs = dothers[:nq], dothers[nq:nq + na], dothers[nq + na:]
         nb = len(cfg.blocks)
+        if ctx.run is not None:
+            run = ctx.run
+            if any(d is not None for d in datts) or any(d is not None for d in dencs):
+                raise L.DevitError("gradients into the exposed 'attention' / 'encoder' outputs run on the granular path only: "
+                                   "set devit_amd.ops.COMPOSITE = False for this model call")
+            B, N, D = run.dims
+            if dx is None:
+                dx = torch.zeros((B, N, D), dtype=F32, device=run.x.device)
+            dx_in = _encoder_backward_composite(run, cfg, dx.contiguous(), dqkvs if nq else None)
+            ctx.run = None
+            return (dx_in, None) + (None,) * (12 * nb)
         B, N, D = saved[0]["x"].shape
         if dx is None:
             dx = torch.zeros((B, N, D), dtype=F32, device=saved[0]["x"].device)

@@ -140,6 +140,78 @@ int devit_attn_bwd(const void* qkv, const void* out, const void* dout, const flo
                    const void* dqkv_add, void* dqkv, int B, int N, int H, int head_dim, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Whole encoder blocks per call.  Replaces Block.forward (models/de_vit.py:103-121: norm1 -> Attention :65-87 ->
+ * DropPath + residual -> norm2 -> Mlp :35-47 -> DropPath + residual) and its autograd backward as ONE host call that
+ * enqueues the block's 8 (forward) / 14 (backward) kernels -- the same kernels, arguments and order as the
+ * single-kernel entry points above, so results are bit-identical to calling those one by one.  It exists to take the
+ * host out of the step: a DEKD step is ~650 launches, and a Python/ctypes round trip per launch costs more than the
+ * kernels take (19 ms of host time for a 28 ms step).  All memory is the caller's; nothing is allocated here.
+ *
+ *   devit_block_weights : device pointers of one block's parameters (bf16 GEMM copies + fp32 biases / LN params / gates)
+ *   devit_block_acts    : one block forward's activations; buffer sizes from devit_block_acts_sizes (index = DEVIT_ACT_*).
+ *                         bf16 row buffers have pad_rows(M) = ceil(M / 256) * 256 rows (qkv: + 128 when flagged) and
+ *                         their rows >= M are zeroed by the forward (GEMM tiles read them, the weight-gradient GEMMs
+ *                         reduce over them).  Pointers of buffers whose size is reported 0 may be NULL.
+ *   flags               : DEVIT_BLK_SAVE   keep what backward needs (mean/rstd, lse, fc1 pre-activation)
+ *                         DEVIT_BLK_QKV_PAD 128 zeroed overhang rows behind qkv (read by the relation-loss Gram windows)
+ *                         DEVIT_BLK_ATT    also store the attention-branch output (pre-residual, de_vit.py:119) as bf16
+ *   devit_encoder_fwd   : blocks 0..nblocks-1 in sequence; acts[i].x2 feeds acts[i+1].x (the caller points them at the
+ *                         same memory); flags per block.
+ *   devit_block_bwd     : gradient of one block.  io->dx = d loss / d x2 (fp32), io->g2 = bf16(dp2 * dx) with zero pad
+ *                         rows; produces io->dx_in and (optional) io->g_prev = bf16(prev_dp2 * dx_in) for the block
+ *                         below together with that block's fc2 bias gradient (column sums, io->prev_fc2_b_grad);
+ *                         weight gradients are ACCUMULATED into devit_block_wgrads (fp32).  io->dqkv_add: gradient
+ *                         arriving at the packed qkv output from outside the block (relation loss) or NULL.
+ *                         The seven transient buffers are sized by devit_block_bwd_sizes and may be reused by the next
+ *                         call; their pad rows are zeroed here.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *n1w, *n1b, *qkv_b, *proj_b, *n2w, *n2b, *fc1_b, *fc2_b;
+  const void *qkv_w16, *proj_w16, *fc1_w16, *fc2_w16;   /* bf16 [out][in] */
+  const float *head_gate, *neuron_gate;                 /* [heads] / [hidden] or NULL (= 1) */
+  int num_heads, attn_width, hidden;                    /* attn_width = heads * 64 (== D unless compacted) */
+} devit_block_weights;
+
+typedef struct {
+  float *n1w, *n1b, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2w, *n2b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} devit_block_wgrads;
+
+enum { DEVIT_ACT_LN1 = 0, DEVIT_ACT_MEAN1, DEVIT_ACT_RSTD1, DEVIT_ACT_QKV, DEVIT_ACT_ATTN_O, DEVIT_ACT_LSE, DEVIT_ACT_X1,
+       DEVIT_ACT_ATT, DEVIT_ACT_LN2, DEVIT_ACT_MEAN2, DEVIT_ACT_RSTD2, DEVIT_ACT_H, DEVIT_ACT_H_PRE, DEVIT_ACT_X2,
+       DEVIT_ACT_COUNT };
+enum { DEVIT_BLK_SAVE = 1, DEVIT_BLK_QKV_PAD = 2, DEVIT_BLK_ATT = 4 };
+
+typedef struct {
+  const float* x;          /* in: fp32 [M][D] residual stream */
+  void* buf[DEVIT_ACT_COUNT];
+  const float *dp1, *dp2;  /* per-sample DropPath scales [B] of the two branches or NULL */
+  int flags;
+} devit_block_acts;
+
+enum { DEVIT_BWD_DH_PRE = 0, DEVIT_BWD_DLN2, DEVIT_BWD_DX1, DEVIT_BWD_G1, DEVIT_BWD_DATTN, DEVIT_BWD_DQKV, DEVIT_BWD_DLN1,
+       DEVIT_BWD_LNWS, DEVIT_BWD_COUNT };
+
+typedef struct {
+  const float* dx;         /* in: fp32 [M][D] */
+  const void* g2;          /* in: bf16 [pad_rows(M)][D] */
+  float* dx_in;            /* out: fp32 [M][D] */
+  void* g_prev;            /* out: bf16 [pad_rows(M)][D] or NULL */
+  const float* prev_dp2;   /* [B] or NULL */
+  float* prev_fc2_b_grad;  /* [D] accumulated, or NULL */
+  int g2_bias_done;        /* != 0: this block's fc2 bias gradient was already produced by the block above */
+  const void* dqkv_add;    /* bf16, qkv layout, or NULL */
+  void* ws[DEVIT_BWD_COUNT];
+  size_t lnws_bytes;
+} devit_block_bwd_io;
+
+int devit_block_acts_sizes(int B, int N, int D, int attn_width, int hidden, int flags, size_t* sizes /* [DEVIT_ACT_COUNT] */);
+int devit_block_bwd_sizes(int B, int N, int D, int attn_width, int hidden, size_t* sizes /* [DEVIT_BWD_COUNT] */);
+int devit_encoder_fwd(int nblocks, const devit_block_weights* w, const devit_block_acts* acts, int B, int N, int D,
+                      float eps, void* stream);
+int devit_block_bwd(const devit_block_weights* w, const devit_block_acts* acts, const devit_block_wgrads* grads,
+                    const devit_block_bwd_io* io, int B, int N, int D, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Patch embedding helpers (timm PatchEmbed used at models/de_vit.py:166-168,258 and token assembly
  * :259-264).  im2row: f32 [B,3,224,224] -> bf16 [B*196][768] with k = c*256 + kh*16 + kw; the
  * projection itself is devit_gemm_bf16 with DEVIT_EPI_PATCH_F32.  embed_tokens writes

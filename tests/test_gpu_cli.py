@@ -19,7 +19,7 @@ def test_distill_sub_cli(tmp_path):
                               "--teacher-model", "deit_base_distilled_patch16_224", "--dataset", "cifar100",
                               "--num_division", "4", "--output_dir", str(tmp_path), "--warmup-epochs", "0"])
     distill_sub.main(args)
-    out = args.output_dir
+    out = os.path.join(args.output_dir, "sub-dataset0")          # distill_sub.py:403-404
     assert os.path.exists(os.path.join(out, "checkpoint_temp.pth")) and os.path.exists(os.path.join(out, "log.txt"))
     ck = torch.load(os.path.join(out, "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
     assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch", "model_ema", "scaler", "args"}
@@ -43,16 +43,16 @@ def test_distill_sub_resume(tmp_path):
     parse = lambda extra: argparse.ArgumentParser(parents=[distill_sub.get_args_parser()]).parse_args(base + extra)
     a1 = parse(["--epochs", "1", "--output_dir", str(tmp_path / "a")])
     distill_sub.main(a1)
-    ck_path = os.path.join(a1.output_dir, "checkpoint_temp.pth")
+    ck_path = os.path.join(a1.output_dir, "sub-dataset0", "checkpoint_temp.pth")
     ck = torch.load(ck_path, map_location="cpu", weights_only=False)
     assert ck["epoch"] == 0 and ck["optimizer"]["step"] == 8 and ck["optimizer"]["ema"] is not None
     # --resume --eval: the restored model is the saved one (evaluate is deterministic on the synthetic val split)
     a2 = parse(["--epochs", "2", "--output_dir", str(tmp_path / "b"), "--resume", ck_path])
     distill_sub.main(a2)
     assert a2.start_epoch == 1
-    lines = [json.loads(l) for l in open(os.path.join(a2.output_dir, "log.txt")).read().splitlines()]
+    lines = [json.loads(l) for l in open(os.path.join(a2.output_dir, "sub-dataset0", "log.txt")).read().splitlines()]
     assert [l["epoch"] for l in lines] == [1] and lines[0]["train_loss"] == lines[0]["train_loss"]
-    ck2 = torch.load(os.path.join(a2.output_dir, "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
+    ck2 = torch.load(os.path.join(a2.output_dir, "sub-dataset0", "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
     assert ck2["epoch"] == 1 and ck2["optimizer"]["step"] == 16
     moved = max(float((ck2["model"][k].float() - ck["model"][k].float()).abs().max()) for k in ck["model"])
     assert 0 < moved < 0.1                     # continued from the checkpoint, not from a fresh initialisation
@@ -77,16 +77,16 @@ def test_distill_sub_finetune_and_eval(tmp_path, capsys):
     parse = lambda extra: argparse.ArgumentParser(parents=[distill_sub.get_args_parser()]).parse_args(base + extra)
     a = parse(["--output_dir", str(tmp_path / "ft"), "--model-path", str(tmp_path / "pre.pth"), "--finetune"])
     distill_sub.main(a)
-    ck = torch.load(os.path.join(a.output_dir, "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
+    ck = torch.load(os.path.join(a.output_dir, "sub-dataset0", "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
     assert ck["model"]["head.weight"].shape == (25, 384) and ck["model"]["head_dist.weight"].shape == (25, 384)
     # two steps at lr ~4e-6 leave the backbone next to the pretrained weights (it was loaded, not re-initialised)
     k = "blocks.5.mlp.fc1.weight"
     assert float((ck["model"][k] - pre.state_dict()[k]).abs().max()) < 1e-3
     capsys.readouterr()
-    e = parse(["--output_dir", str(tmp_path / "ev"), "--resume", os.path.join(a.output_dir, "checkpoint_temp.pth"), "--eval"])
+    e = parse(["--output_dir", str(tmp_path / "ev"), "--resume", os.path.join(a.output_dir, "sub-dataset0", "checkpoint_temp.pth"), "--eval"])
     distill_sub.main(e)
     printed = capsys.readouterr().out
-    assert "acc1" in printed and not os.path.exists(os.path.join(e.output_dir, "log.txt"))
+    assert "acc1" in printed and not os.path.exists(os.path.join(e.output_dir, "sub-dataset0", "log.txt"))
 
 
 def test_ensemble_cli(tmp_path):
@@ -197,3 +197,115 @@ def test_ensemble_cli_checkpoints_gates_shrink(tmp_path, capsys):
         if extra:
             assert "physically shrunk 48 blocks" in out
     assert abs(scores[0][0] - scores[1][0]) < 2e-2 * abs(scores[0][0]) and scores[0][1:] == scores[1][1:]
+
+
+def test_distill_sub_to_ensemble_chain(tmp_path):
+    """distill_sub.py writes `<out>/sub-dataset{k}/checkpoint.pth` (distill_sub.py:403-404,446-449) and ensemble.py reads
+    `{--model-path}/sub-dataset{i}/checkpoint.pth` (ensemble.py:228): four divisions trained by the first CLI feed the
+    second with NO file moved in between."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import json
+    import distill_sub
+    import ensemble
+    outs = set()
+    for k in range(4):
+        a = argparse.ArgumentParser(parents=[distill_sub.get_args_parser()]).parse_args(
+            ["--synthetic", "2", "--batch-size", "4", "--epochs", "1", "--model", "dedeit", "--teacher-model",
+             "deit_base_distilled_patch16_224", "--dataset", "cifar100", "--num_division", "4", "--start-division", str(k),
+             "--output_dir", str(tmp_path / "distill"), "--warmup-epochs", "0"])
+        distill_sub.main(a)
+        outs.add(a.output_dir)
+        # eval accuracy on random labels can be 0 and then no best checkpoint is written (max_accuracy < acc1 is strict,
+        # distill_sub.py:445): the chain needs the file, so fall back to the epoch checkpoint's model like a user would
+        best = os.path.join(a.output_dir, f"sub-dataset{k}", "checkpoint.pth")
+        if not os.path.exists(best):
+            ck = torch.load(os.path.join(a.output_dir, f"sub-dataset{k}", "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
+            torch.save(ck["model"], best)
+    assert len(outs) == 1                                  # one run directory, four sub-dataset{k} children
+    model_path = outs.pop()
+    e = argparse.ArgumentParser(parents=[ensemble.get_args_parser()], conflict_handler='resolve').parse_args(
+        ["--synthetic", "2", "--batch-size", "4", "--epochs", "1", "--model", "dedeit", "--teacher-model",
+         "deit_base_distilled_patch16_224", "--model-path", model_path, "--output_dir", str(tmp_path / "ens")])
+    assert e.clip_grad is None and e.weight_decay == 0.05 and e.epochs == 1 and e.lr == 1e-5     # ensemble.py:41,68,72,77
+    assert argparse.ArgumentParser(parents=[ensemble.get_args_parser()], conflict_handler='resolve').parse_args([]).epochs == 3
+    e.output_dir = str(tmp_path / "ens")
+    os.makedirs(e.output_dir, exist_ok=True)
+    ensemble.main(e)
+    line = json.loads(open(os.path.join(e.output_dir, "log.txt")).read().splitlines()[-1])
+    assert line["train_loss"] == line["train_loss"]
+    ck = torch.load(os.path.join(e.output_dir, "checkpoint_temp.pth"), map_location="cpu", weights_only=False)
+    assert {"model", "ens_model", "optimizer", "ens_optimizer", "lr_scheduler", "ens_lr_scheduler", "epoch", "scaler", "args"} <= set(ck)
+    # the backbones really came from the four distill_sub checkpoints (positional copy), then trained one tiny epoch
+    sub0 = torch.load(os.path.join(model_path, "sub-dataset0", "checkpoint.pth"), map_location="cpu")
+    k0 = [k for k in ck["model"] if k.endswith("blocks.0.attn.qkv.weight")][0]
+    assert float((ck["model"][k0] - sub0["blocks.0.attn.qkv.weight"]).abs().max()) < 1e-3
+
+
+def test_distill_sub_shrink_flags(tmp_path):
+    """--shrink_checkpoint / --neuron_shrinking / --head_shrinking (distill_sub.py:383-401): the policy files are read,
+    one batch is ranked, the student trains GATED (never silently dense), the gates are persisted; a shrink flag without
+    a policy directory is an error; unsupported --opt / --sched values are refused."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import numpy as np
+    import distill_sub
+    from devit_amd import shrink
+    pol = np.zeros((3, 24))
+    pol[1, :12], pol[1, 12:] = 0.25, 0.34            # best row: 25 % of the neurons, int(6 * .66) = 3 heads kept -> 3 off
+    pol[0], pol[2] = 0.5, 0.1
+    os.makedirs(tmp_path / "shrink")
+    np.save(tmp_path / "shrink" / "shrinked_policy.npy", pol)
+    np.save(tmp_path / "shrink" / "shrinked_accuracy.npy", np.array([10.0, 80.0, 30.0]))
+    ns, hs = shrink.read_shrink_checkpoint(str(tmp_path / "shrink"))
+    assert np.allclose(ns, 0.25) and np.allclose(hs, 0.34) and len(hs) == 12
+    np.save(tmp_path / "shrink" / "p25.npy", np.concatenate([pol, np.ones((3, 1))], 1))      # 25-column files work too
+    base = ["--synthetic", "2", "--batch-size", "4", "--epochs", "1", "--model", "dedeit", "--teacher-model",
+            "deit_base_distilled_patch16_224", "--dataset", "cifar100", "--num_division", "4", "--warmup-epochs", "0"]
+    parse = lambda extra: argparse.ArgumentParser(parents=[distill_sub.get_args_parser()]).parse_args(base + extra)
+    a = parse(["--output_dir", str(tmp_path / "o"), "--shrink_checkpoint", str(tmp_path / "shrink"), "--neuron_shrinking",
+               "--head_shrinking"])
+    distill_sub.main(a)
+    gates = torch.load(os.path.join(a.output_dir, "sub-dataset0", "gates.pt"), weights_only=False) \
+        if os.path.exists(os.path.join(a.output_dir, "sub-dataset0", "gates.pt")) else None
+    if gates is not None:                             # written with the best checkpoint (needs acc1 > 0 on random labels)
+        assert all(int(h.sum()) == 3 and int(n.sum()) == 1152 for h, n in gates)
+    with pytest.raises(ValueError):
+        distill_sub.main(parse(["--output_dir", str(tmp_path / "p"), "--neuron_shrinking"]))
+    for bad in (["--opt", "sgd"], ["--sched", "step"]):
+        with pytest.raises(SystemExit):
+            distill_sub.main(parse(["--output_dir", str(tmp_path / "q")] + bad))
+
+
+def test_rank_units_and_masks(tmp_path):
+    """shrink.rank_units -> masks_from_sparsity: the kept units are the highest-ranked ones and the gated forward's
+    neuron_output / head_output are zero exactly on the masked units (the contract core/imp_rank.py relies on)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import devit_amd
+    from devit_amd import shrink
+    dev = torch.device("cuda")
+    torch.manual_seed(2)
+    m = devit_amd.create_model("dedeit", num_classes=25).to(dev)
+    loader = [(torch.randn(6, 3, 224, 224, device=dev), torch.zeros(6, dtype=torch.long, device=dev))]
+    nr, hr = shrink.rank_units(m, loader, dev)
+    assert len(nr) == 12 and len(hr) == 12 and sorted(nr[0].tolist()) == list(range(1536)) and sorted(hr[3].tolist()) == list(range(6))
+    # the activation-mass term dominates the neuron score (0.9 weight): the top-ranked neuron carries far more |activation|
+    # than the bottom-ranked one
+    act = m.blocks[0].mlp.neuron_output.float().abs().sum((0, 1))
+    assert float(act[nr[0][-1]]) > float(act[nr[0][0]])
+    pol = shrink.masks_from_sparsity(m, [0.5] * 12, [0.34] * 12, nr, hr)
+    shrink.load_policy(m, pol)
+    m.eval()
+    with torch.no_grad():
+        m(loader[0][0])
+    for i in (0, 7):
+        hm, nm = pol[i]
+        assert int(hm.sum()) == 3 and int(nm.sum()) == 768
+        assert set(torch.nonzero(nm).reshape(-1).tolist()) == set(nr[i][::-1][:768].tolist())
+        no = m.blocks[i].mlp.neuron_output.float().abs().sum((0, 1)).cpu()
+        ho = m.blocks[i].attn.head_output.float().abs().sum((0, 1, 3)).cpu()
+        assert bool((no[nm == 0] == 0).all()) and bool((no[nm == 1] > 0).all())
+        assert bool((ho[hm == 0] == 0).all()) and bool((ho[hm == 1] > 0).all())

@@ -416,3 +416,43 @@ def test_step_other_class_counts(dev, classes):
               "blocks.7.mlp.fc2.bias", "blocks.2.attn.proj.bias",      # column sums fused into the LayerNorm backward
               "blocks.4.norm1.weight", "blocks.4.norm2.bias"):
         assert chk(rel(got[k].grad, leaf[k].grad.numpy()), 6e-2), k
+
+
+# ------------------------------------------------------------------------------------------ composite block calls
+@pytest.mark.parametrize("bs", [3, 8])
+def test_block_calls_match_granular_path(models, dev, bs):
+    """devit_encoder_fwd / devit_block_bwd (one host call per encoder / per block, csrc/encoder.hip) enqueue the same
+    kernels with the same arguments in the same order as the one-call-per-kernel path: forward results and the
+    input gradient are bit-identical, weight gradients agree to the order of their fp32 atomics.  bs 3 = 594 token rows:
+    the zeroed pad rows (594 -> 768) of every buffer are the composite call's own job."""
+    from devit_amd import engine, ops
+    s, t, _, _ = models
+    img = torch.from_numpy(det_array("img8", (8, 3, 224, 224)))[:bs].to(dev)
+    soft = torch.softmax(torch.from_numpy(det_array("comp_soft", (bs, C), std=2.0)), 1).to(dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    dps = []
+    for i in range(12):
+        keep = 1.0 - 0.1 * i / 11
+        sc = torch.floor(keep + torch.rand((2, bs), generator=g, device=dev)) / keep
+        dps.append((sc[0].contiguous(), sc[1].contiguous()))
+    res = {}
+    s.train()
+    try:
+        for mode in (False, True):
+            ops.COMPOSITE = mode
+            for p in s.parameters():
+                p.grad = None
+            x = img.clone().requires_grad_(True)
+            out = engine.distill_forward(s, t, x, soft, dp_scales=dps)
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            res[mode] = (out["loss"].detach().clone(), out["logits"][0].detach().clone(), out["teacher_logits"].detach().clone(),
+                         {n: p.grad.detach().clone() for n, p in s.named_parameters()})
+    finally:
+        ops.COMPOSITE = True
+        for p in s.parameters():
+            p.grad = None
+    (l0, lo0, tl0, g0), (l1, lo1, tl1, g1) = res[False], res[True]
+    assert torch.equal(lo0, lo1) and torch.equal(tl0, tl1) and torch.equal(l0, l1)
+    for n in g0:
+        assert chk(rel(g1[n], g0[n].cpu().numpy()), 2e-5), n          # split-K atomics: summation order only
