@@ -272,6 +272,14 @@ def main():
     t_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (no device wait inside)
     fence()
     dt = time.perf_counter() - t0
+    # host cost of one step with nothing in the way: the device idle and its queue empty when the enqueue starts
+    # (`host_enqueue_ms_per_step` above also contains the time the host sits blocked on a full launch queue once it is
+    # several steps ahead of the GPU)
+    t1 = time.perf_counter()
+    step()
+    step()
+    host_step_ms = (time.perf_counter() - t1) / 2 * 1e3
+    fence()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -361,6 +369,7 @@ def main():
             "metric": "images/sec distill_sub step (DeiT-B->dedeit, bs256, 224^2)", "value": round(img_per_s, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
+            "host_ms_per_step_idle_queue": round(host_step_ms, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic, pinned host batches through PCIe every step" if args.host_input else "synthetic",
             "config": {"workload": f"distill_sub step dedeit<-deit_base_distilled_patch16_224, num_division=4 "

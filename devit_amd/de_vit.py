@@ -43,6 +43,7 @@ class _Gated:
     def _init_gate(self, n):
         self._gate = torch.ones(n)
         self._gate_dev = None
+        self._gate_ones = True
 
     @property
     def gate(self):
@@ -52,10 +53,13 @@ class _Gated:
     def gate(self, value):
         self._gate = value
         self._gate_dev = None
+        self._gate_ones = None        # unknown until the next forward looks (the shrink code ASSIGNS gates, imp_rank.py:65-71)
 
     def gate_on(self, device):
         g = self._gate
-        if bool((g == 1).all()):
+        if self._gate_ones is None:
+            self._gate_ones = bool((g == 1).all())
+        if self._gate_ones:
             return None
         if self._gate_dev is None or self._gate_dev.device != device:
             self._gate_dev = g.detach().float().to(device).contiguous()
@@ -131,6 +135,22 @@ class Block(nn.Module):
         return self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.
 
     def block_params(self, device):
+        """Parameter view of this block for ops.EncoderFn, cached between calls: rebuilt when a weight was rewritten
+        (version counter / storage), a gate was assigned, the block was (un)compacted or switched train / eval."""
+        c = getattr(self, "_compact", None)
+        a, m_ = self.attn, self.mlp
+        key = (device, self.training, self.drop_prob, id(c), id(a._gate), id(m_._gate),
+               id(a.qkv.__dict__.get("_w16")), id(a.proj.__dict__.get("_w16")), id(m_.fc1.__dict__.get("_w16")),
+               id(m_.fc2.__dict__.get("_w16")), a.qkv.weight._version, a.proj.weight._version, m_.fc1.weight._version, m_.fc2.weight._version,
+               a.qkv.weight.data_ptr(), a.proj.weight.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc2.weight.data_ptr())
+        cached = getattr(self, "_bp_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        bp = self._build_block_params(device)
+        self._bp_cache = (key, bp)
+        return bp
+
+    def _build_block_params(self, device):
         bp = ops.BlockParams()
         bp.compacted = False
         c = getattr(self, "_compact", None)

@@ -12,7 +12,32 @@ import sys
 
 import torch
 
-from . import de_vit, losses
+from . import de_vit, losses, ops
+
+
+def _hand_over(out, main):
+    """Outputs of a side-stream forward that the main stream will read.  Small tensors from the side stream's allocator
+    pool are marked with record_stream(); the packed qkv buffers of the composite path are views of an arena that was
+    allocated from the MAIN stream's pool (ops.ARENA_ALLOC_STREAM) and need no mark -- see the note there."""
+    o = out['output']
+    for t in (o if isinstance(o, tuple) else (o,)):
+        t.record_stream(main)
+    for qkv in out['qkv']:
+        if qkv is None:
+            continue
+        packed = getattr(qkv[0], "_devit_packed", (qkv[0],))[0]
+        if packed.untyped_storage().nbytes() <= packed.numel() * packed.element_size():    # its own allocation
+            packed.record_stream(main)
+
+
+def _side_forward(teacher_model, samples, main, side):
+    side.wait_stream(main)
+    prev, ops.ARENA_ALLOC_STREAM = ops.ARENA_ALLOC_STREAM, main
+    try:
+        with torch.cuda.stream(side), torch.no_grad():
+            return teacher_model(samples, output_qkv=True)
+    finally:
+        ops.ARENA_ALLOC_STREAM = prev
 
 
 def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0,
@@ -59,14 +84,9 @@ def _teacher_forward(teacher_model, samples):
             return teacher_model(samples, output_qkv=True)
     main = torch.cuda.current_stream()
     side = _side_stream.setdefault(samples.device.index, torch.cuda.Stream())
-    side.wait_stream(main)          # NOTE: call this BEFORE the student forward is enqueued to get overlap
-    with torch.cuda.stream(side), torch.no_grad():
-        out = teacher_model(samples, output_qkv=True)
+    out = _side_forward(teacher_model, samples, main, side)   # NOTE: call BEFORE the student forward is enqueued to overlap
     main.wait_stream(side)
-    out['output'].record_stream(main)
-    for qkv in out['qkv']:
-        q = qkv[0]
-        getattr(q, "_devit_packed", (q,))[0].record_stream(main)
+    _hand_over(out, main)
     return out
 
 
@@ -74,15 +94,11 @@ def _teacher_forward_async(teacher_model, samples):
     """Enqueue the teacher forward on the side stream now; the returned callable joins it."""
     main = torch.cuda.current_stream()
     side = _side_stream.setdefault(samples.device.index, torch.cuda.Stream())
-    side.wait_stream(main)
-    with torch.cuda.stream(side), torch.no_grad():
-        out = teacher_model(samples, output_qkv=True)
+    out = _side_forward(teacher_model, samples, main, side)
 
     def join():
         main.wait_stream(side)
-        out['output'].record_stream(main)
-        for qkv in out['qkv']:
-            getattr(qkv[0], "_devit_packed", (qkv[0],))[0].record_stream(main)
+        _hand_over(out, main)
         return out
     return join
 

@@ -321,7 +321,21 @@ def scale_cast(dx, rowscale, N):
 # ~15 torch allocations per block.  COMPOSITE = False forces the granular path (A/B tests).
 # ----------------------------------------------------------------------------------------------
 COMPOSITE = os.environ.get("DEVIT_COMPOSITE", "1") == "1"
+# Stream whose allocator pool the encoder arenas come from (None: the current stream).  A forward that runs on a side
+# stream but is consumed on the main stream (the frozen teacher, engine._teacher_forward_async) sets this to the
+# CONSUMER's stream: a 13 GB arena handed across streams with Tensor.record_stream() comes back to the allocator only when
+# the recorded event has completed, i.e. a step later -- the host, which runs ahead, would hipMalloc a fresh arena every
+# step (measured: 180 ms of host time per step).  With the arena in the consumer's pool the hand-over is ordered by the
+# wait_stream() calls that are there anyway (producer starts after the consumer stream's tail, consumer joins the producer).
+ARENA_ALLOC_STREAM = None
 _sizes_cache = {}
+
+
+def _arena(nbytes, dev):
+    if ARENA_ALLOC_STREAM is not None and dev.type == "cuda":
+        with torch.cuda.stream(ARENA_ALLOC_STREAM):
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
 _ACT_DT = {L.ACT_LN1: BF16, L.ACT_QKV: BF16, L.ACT_ATTN_O: BF16, L.ACT_ATT: BF16, L.ACT_LN2: BF16, L.ACT_H: BF16,
            L.ACT_H_PRE: BF16}
 
@@ -376,35 +390,32 @@ def _encoder_forward_composite(x, cfg, need_grad):
     mp = pad_rows(M)
     weights = (L.BlockWeights * nb)()
     acts = (L.BlockActs * nb)()
-    layouts, total = [], 0
+    run = _EncoderRun()
+    # one allocation per block (uniform sizes: the caching allocator hands the same blocks back every step; a single
+    # 8-13 GB arena per encoder call gets split by other requests and re-hipMalloc'ed -- measured 150 ms of host per step)
+    run.weights, run.acts, run.arena, run.x, run.dims, run.dps = weights, acts, [], x, (B, N, D), cfg.dp_scales
+    views = []
+    x_ptr = x.data_ptr()
     for i, bp in enumerate(cfg.blocks):
         weights[i] = _weights_struct(bp)
         pad = bool(cfg.want_qkv) and (cfg.qkv_pad_layers is None or i in cfg.qkv_pad_layers)
         flags = (L.BLK_SAVE if need_grad else 0) | (L.BLK_QKV_PAD if pad else 0) | (L.BLK_ATT if cfg.want_att else 0)
-        sz, offs, tot = _act_sizes(B, N, D, weights[i].attn_width, weights[i].hidden, flags)
-        layouts.append((flags, sz, offs, total))
-        total += tot
-    arena = torch.empty(total, dtype=torch.uint8, device=dev)
-    base = arena.data_ptr()
-    run = _EncoderRun()
-    run.weights, run.acts, run.arena, run.x, run.dims, run.dps = weights, acts, arena, x, (B, N, D), cfg.dp_scales
-    views = []
-    x_ptr = x.data_ptr()
-    for i, bp in enumerate(cfg.blocks):
-        flags, sz, offs, off0 = layouts[i]
+        Da, Hd = weights[i].attn_width, weights[i].hidden
+        sz, offs, tot = _act_sizes(B, N, D, Da, Hd, flags)
+        arena = _arena(tot, dev)
+        run.arena.append(arena)
+        base = arena.data_ptr()
         a = acts[i]
         a.x = x_ptr
         for j in range(L.ACT_COUNT):
-            a.buf[j] = base + off0 + offs[j] if sz[j] else None
+            a.buf[j] = base + offs[j] if sz[j] else None
         dp = cfg.dp_scales[i] if cfg.dp_scales is not None else None
         a.dp1, a.dp2 = (_p(dp[0]), _p(dp[1])) if dp is not None else (None, None)
         a.flags = flags
         x_ptr = a.buf[L.ACT_X2]
-        Da, Hd = weights[i].attn_width, weights[i].hidden
 
-        def view(j, rows, cols, dt, off0=off0, offs=offs):
-            o = off0 + offs[j]
-            return arena[o:o + rows * cols * dt.itemsize].view(dt).view(rows, cols)
+        def view(j, rows, cols, dt, arena=arena, offs=offs):
+            return arena[offs[j]:offs[j] + rows * cols * dt.itemsize].view(dt).view(rows, cols)
         qkv_rows = mp + (128 if flags & L.BLK_QKV_PAD else 0)
         v = dict(qkv=view(L.ACT_QKV, qkv_rows, 3 * Da, BF16), x2=view(L.ACT_X2, M, D, F32).view(B, N, D),
                  att=view(L.ACT_ATT, M, D, BF16) if cfg.want_att else None)

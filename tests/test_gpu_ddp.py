@@ -79,20 +79,19 @@ def test_real_model_reports_every_parameter_once_and_buckets_overlap():
     # heads' bucket first, the patch embedding's last
     assert flat.names[0].startswith("head") and flat.names[-1] in ("cls_token", "pos_embed", "dist_token")
     assert flat.grad_scale == 0.5
-    torch.testing.assert_close(flat.flat_grad, 2.0 * local, rtol=0, atol=0)              # same kernels, same order: exact
+    # same kernels in the same order; the split-K weight gradients leave through fp32 atomics, so up to summation order
+    torch.testing.assert_close(flat.flat_grad, 2.0 * local, rtol=1e-4, atol=1e-5 * float(local.abs().max()))
 
-    # the optimizer folds 1 / world back in: same update as a single-rank step on the local gradient
-    w0 = flat.flat.clone()
+    # the optimizer kernel folds 1 / world back in (devit_adamw_step's grad_scale): after one step from zero moments the
+    # first moment is (1 - beta1) * clip * mean gradient, with the clip factor computed from the MEAN gradient's norm
     opt = optim.FlatAdamW(flat, lr=1e-3, max_norm=1.0)
     opt.step()
     torch.cuda.synchronize()
-    w_ddp = flat.flat.clone()
-    flat.flat.copy_(w0)
-    flat.flat_grad.copy_(local)
-    opt2 = optim.FlatAdamW(flat, lr=1e-3, max_norm=1.0)
-    opt2.step()
-    torch.cuda.synchronize()
-    torch.testing.assert_close(w_ddp, flat.flat, rtol=1e-6, atol=1e-9)
+    assert flat.grad_scale == 1.0                                  # consumed
+    nrm = float(local.double().norm())
+    clip = min(1.0, 1.0 / (nrm + 1e-6))
+    torch.testing.assert_close(opt.m, 0.1 * clip * local, rtol=1e-4, atol=1e-5 * clip * float(local.abs().max()))
+    torch.testing.assert_close(float(opt.gnorm_sq) ** 0.5, 2.0 * nrm, rtol=1e-4, atol=0)   # the raw buffer held the sum
 
 
 def test_weight_decay_groups_match_torch_adamw():
@@ -119,4 +118,5 @@ def test_weight_decay_groups_match_torch_adamw():
         params[name].grad = g[o:o + p.numel()].view_as(p).clone()
     topt.step()
     for n, p in m.named_parameters():
-        torch.testing.assert_close(p.detach(), params[n].detach(), rtol=2e-6, atol=2e-8, msg=n)
+        d = float((p.detach() - params[n].detach()).abs().max())
+        assert d < 1e-6, (n, d, float((p.detach() - ref[n]).abs().max()))

@@ -67,10 +67,10 @@ def test_model_forward_vs_golden(golden, models, dev, which):
     q, k, v = d["qkv"][5]
     D = m.embed_dim
     assert q.shape == (8, D // 64, 198, 64) and q.stride() == (198 * 3 * D, 64, 3 * D, 1)
-    assert chk(rel(q[:2, :, :24], g["q5"]), 3e-2) and chk(rel(k[:2, :, :24], g["k5"]), 3e-2) and chk(rel(v[:2, :, :24], g["v5"]), 3e-2)
-    assert chk(rel(d["attention"][5][:2, :24], g["att5"]), 3e-2)
-    assert chk(rel(d["encoder"][-1][:2, :24], g["enc_last"]), 3e-2)
-    assert chk(rel(d["last_tokens"][0], g["last_cls"]), 3e-2) and chk(rel(d["last_tokens"][1], g["last_dist"]), 3e-2)
+    assert chk(rel(q[:2, :, :24], g["q5"]), 2e-2) and chk(rel(k[:2, :, :24], g["k5"]), 2e-2) and chk(rel(v[:2, :, :24], g["v5"]), 2e-2)
+    assert chk(rel(d["attention"][5][:2, :24], g["att5"]), 2e-2)
+    assert chk(rel(d["encoder"][-1][:2, :24], g["enc_last"]), 2e-2)
+    assert chk(rel(d["last_tokens"][0], g["last_cls"]), 2e-2) and chk(rel(d["last_tokens"][1], g["last_dist"]), 2e-2)
     es = np.stack([[x.mean().item(), x.abs().mean().item()] for x in d["encoder"]])
     assert np.abs(es - g["enc_stats"]).max() < 2e-2 * np.abs(g["enc_stats"]).max()
     m.train()
@@ -79,7 +79,7 @@ def test_model_forward_vs_golden(golden, models, dev, which):
         assert isinstance(tr, tuple) and len(tr) == 2
         from devit_amd import engine    # golden train outputs were captured with drop_path = 0
         tr = engine._forward_with_dp(m, img, None)["output"]
-    assert chk(rel(tr[0], g["train_cls"]), 3e-2) and chk(rel(tr[1], g["train_dist"]), 3e-2)
+    assert chk(rel(tr[0], g["train_cls"]), 2e-2) and chk(rel(tr[1], g["train_dist"]), 2e-2)
     m.eval() if which == "deitb" else None
 
 
@@ -94,31 +94,31 @@ def test_modules_vs_golden(golden, models, dev):
         for p in blk.parameters():
             p.grad = None
         y = blk.mlp(x)
-        assert chk(rel(sub(y), g["mlp_y"]), 2e-2)
+        assert chk(rel(sub(y), g["mlp_y"]), 1e-2)
         y.square().sum().backward()
-        assert chk(rel(sub(x.grad), g["mlp_dx"]), 4e-2)
-        assert chk(rel(blk.mlp.fc1.weight.grad[:8], g["mlp_dw1_rows"]), 4e-2)
+        assert chk(rel(sub(x.grad), g["mlp_dx"]), 1.5e-2)
+        assert chk(rel(blk.mlp.fc1.weight.grad[:8], g["mlp_dw1_rows"]), 1.5e-2)
         blk.mlp.gate = torch.from_numpy(g["neuron_gate"])
         with torch.no_grad():
             y2 = blk.mlp(x)
-        assert chk(rel(sub(y2), g["mlp_y_gated"]), 2e-2)
-        assert chk(rel(blk.mlp.neuron_output.float().sum(dim=(0, 1)), g["mlp_neuron_output_sum"]), 2e-2)   # post-mask (Q3)
+        assert chk(rel(sub(y2), g["mlp_y_gated"]), 1e-2)
+        assert chk(rel(blk.mlp.neuron_output.float().sum(dim=(0, 1)), g["mlp_neuron_output_sum"]), 1e-2)   # post-mask (Q3)
         blk.mlp.gate = torch.ones(4 * D)
         x.grad = None
         a = blk.attn(x, True)
-        assert chk(rel(sub(a["output"]), g["attn_y"]), 2e-2)
-        assert chk(rel(a["qkv"][0][:, :, :16], g["attn_q"]), 2e-2) and chk(rel(a["qkv"][2][:, :, :16], g["attn_v"]), 2e-2)
+        assert chk(rel(sub(a["output"]), g["attn_y"]), 1e-2)
+        assert chk(rel(a["qkv"][0][:, :, :16], g["attn_q"]), 1e-2) and chk(rel(a["qkv"][2][:, :, :16], g["attn_v"]), 1e-2)
         a["output"].square().sum().backward()
-        assert chk(rel(sub(x.grad), g["attn_dx"]), 4e-2)
+        assert chk(rel(sub(x.grad), g["attn_dx"]), 1.5e-2)
         blk.attn.gate = torch.from_numpy(g["head_gate"])
         with torch.no_grad():
             a2 = blk.attn(x, True)
-        assert chk(rel(sub(a2["output"]), g["attn_y_gated"]), 2e-2)
-        assert chk(rel(blk.attn.head_output.float().sum(dim=(0, 1)), g["attn_head_output_sum"]), 2e-2)
+        assert chk(rel(sub(a2["output"]), g["attn_y_gated"]), 1e-2)
+        assert chk(rel(blk.attn.head_output.float().sum(dim=(0, 1)), g["attn_head_output_sum"]), 1e-2)
         blk.attn.gate = torch.ones(H)
         with torch.no_grad():
             b = blk(x, output_qkv=True, output_att=True)
-        assert chk(rel(sub(b["output"]), g["block_y"]), 2e-2) and chk(rel(sub(b["attention"]), g["block_att"]), 2e-2)
+        assert chk(rel(sub(b["output"]), g["block_y"]), 1e-2) and chk(rel(sub(b["attention"]), g["block_att"]), 1e-2)
         for p in blk.parameters():
             p.grad = None
     s.train()
@@ -144,7 +144,7 @@ def test_losses_vs_golden(golden, dev):
     l = devit_amd.feature_relation_loss(tf, sf)
     d, = torch.autograd.grad(l, [sf])
     assert abs(float(l) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))        # bf16 features
-    assert chk(rel(d[:, :, ::9], g["dstudent"]), 4e-2)
+    assert chk(rel(d[:, :, ::9], g["dstudent"]), 1.5e-2)
 
 
 def test_distill_step_vs_golden(golden, models, dev):
@@ -171,14 +171,14 @@ def test_distill_step_vs_golden(golden, models, dev):
     chk(float((np.abs(gn - g["grad_norms"]) / (g["grad_norms"] + 1e-3 * g["grad_norms"].max())).max()), 3e-3)
     bad = np.abs(gn - g["grad_norms"]) > 3e-3 * g["grad_norms"] + 3e-6 * g["grad_norms"].max()      # measured 6e-4
     assert not bad.any(), [(names[i], gn[i], g["grad_norms"][i]) for i in np.nonzero(bad)[0][:8]]
-    assert chk(rel(params["head.weight"].grad, g["g_head_w"]), 1e-2)
-    assert chk(rel(params["blocks.5.attn.qkv.weight"].grad[::48], g["g_qkv5_w_rows"]), 1e-2)
-    assert chk(rel(params["blocks.0.mlp.fc1.weight"].grad[::64], g["g_fc1_0_rows"]), 1e-2)
-    assert chk(rel(params["blocks.11.mlp.fc2.weight"].grad[::16], g["g_fc2_11_rows"]), 1e-2)
-    assert chk(rel(params["pos_embed"].grad[0, ::8], g["g_pos"]), 1e-2)
-    assert chk(rel(params["cls_token"].grad, g["g_cls"]), 1e-2)
-    assert chk(rel(params["patch_embed.proj.weight"].grad[::16].reshape(-1, 768), g["g_patch_w"]), 1e-2)
-    assert chk(rel(params["norm.weight"].grad, g["g_norm_w"]), 1e-2)
+    assert chk(rel(params["head.weight"].grad, g["g_head_w"]), 1.5e-2)
+    assert chk(rel(params["blocks.5.attn.qkv.weight"].grad[::48], g["g_qkv5_w_rows"]), 1.5e-2)
+    assert chk(rel(params["blocks.0.mlp.fc1.weight"].grad[::64], g["g_fc1_0_rows"]), 1.5e-2)
+    assert chk(rel(params["blocks.11.mlp.fc2.weight"].grad[::16], g["g_fc2_11_rows"]), 1.5e-2)
+    assert chk(rel(params["pos_embed"].grad[0, ::8], g["g_pos"]), 1.5e-2)
+    assert chk(rel(params["cls_token"].grad, g["g_cls"]), 1.5e-2)
+    assert chk(rel(params["patch_embed.proj.weight"].grad[::16].reshape(-1, 768), g["g_patch_w"]), 1.5e-2)
+    assert chk(rel(params["norm.weight"].grad, g["g_norm_w"]), 1.5e-2)
     for p in s.parameters():
         p.grad = None
 
@@ -192,7 +192,7 @@ def test_fresh_inputs_vs_oracle(models, dev):
     s.eval()
     with torch.no_grad():
         out = s(img.to(dev))
-    assert chk(rel(out, ref.numpy()), 3e-2)
+    assert chk(rel(out, ref.numpy()), 2e-2)
     assert torch.equal(out.argmax(1).cpu(), ref.argmax(1))
     s.train()
 
@@ -260,17 +260,17 @@ def test_ensemble_vs_golden(golden, dev):
     multi.eval(); ens.eval()
     with torch.no_grad():
         le = ens(multi(img))
-    assert chk(rel(le, g["logits_eval"]), 3e-2) and np.array_equal(le.argmax(1).cpu().numpy(), g["logits_eval"].argmax(1))
+    assert chk(rel(le, g["logits_eval"]), 2e-2) and np.array_equal(le.argmax(1).cpu().numpy(), g["logits_eval"].argmax(1))
     multi.train(); ens.train()
     crit = losses.EnsLoss(losses.SoftTargetCrossEntropy(), teacher, "dedeit", "hard", 0.5, 1.0)
     out = engine.ens_forward(multi, ens, crit, img, torch.from_numpy(g["soft_targets"]).to(dev))
     assert abs(float(out["token_loss"]) - float(g["token_loss"])) < 2e-2 * float(g["token_loss"])
     assert abs(float(out["cls_loss"]) - float(g["cls_loss"])) < 2e-2 * float(g["cls_loss"])
     out["loss"].backward()
-    assert chk(rel(ens.cls_mlp.weight.grad[::48], g["g_cls_mlp_w_rows"]), 6e-2)
-    assert chk(rel(ens.dist_classifier.weight.grad[::10], g["g_dist_cls_w"]), 6e-2)
-    assert chk(rel(multi.backbones[2].blocks[3].mlp.fc1.weight.grad[::96], g["g_b2_fc1_rows"]), 6e-2)
-    assert chk(rel(multi.backbones[0].pos_embed.grad[0, ::16], g["g_b0_pos"]), 6e-2)
+    assert chk(rel(ens.cls_mlp.weight.grad[::48], g["g_cls_mlp_w_rows"]), 2.5e-2)
+    assert chk(rel(ens.dist_classifier.weight.grad[::10], g["g_dist_cls_w"]), 2.5e-2)
+    assert chk(rel(multi.backbones[2].blocks[3].mlp.fc1.weight.grad[::96], g["g_b2_fc1_rows"]), 2.5e-2)
+    assert chk(rel(multi.backbones[0].pos_embed.grad[0, ::16], g["g_b0_pos"]), 2.5e-2)
     # exact-fp32 path on the same graph: the 1e-3 bar
     for m in list(multi.backbones) + [teacher]:
         m.precision = "f32"
@@ -307,8 +307,8 @@ def test_compacted_model_equals_masked_model(models, dev):
             dense_gf, compact_gf = 9.247, shrink.compacted_gflops(s, num_classes=C)
             assert 0.70 * dense_gf < compact_gf < 0.80 * dense_gf
             comp = s(img.to(dev), output_qkv=True)
-        assert chk(rel(comp["output"], masked["output"].float().cpu().numpy()), 5e-3)      # same bf16 path, fewer zero terms
-        assert chk(rel(comp["output"], ref.numpy()), 3e-2) and torch.equal(comp["output"].argmax(1).cpu(), ref.argmax(1))
+        assert chk(rel(comp["output"], masked["output"].float().cpu().numpy()), 1e-2)      # same bf16 path, fewer zero terms
+        assert chk(rel(comp["output"], ref.numpy()), 2e-2) and torch.equal(comp["output"].argmax(1).cpu(), ref.argmax(1))
         assert comp["qkv"][0][0].shape[1] == rep[0][1]                                 # q of block 0: [B, heads run, N, 64]
         assert s.blocks[0].mlp.neuron_output.shape[-1] == 1152
         s.train()
@@ -345,7 +345,7 @@ def test_nondistilled_devit_vs_oracle(dev):
     m.eval()
     with torch.no_grad():
         out_eval = m(img.to(dev))
-    assert chk(rel(out_eval, ref.detach().numpy()), 3e-2) and torch.equal(out_eval.argmax(1).cpu(), ref.argmax(1))
+    assert chk(rel(out_eval, ref.detach().numpy()), 2e-2) and torch.equal(out_eval.argmax(1).cpu(), ref.argmax(1))
     m.train()
     out = m(img.to(dev))
     assert isinstance(out, torch.Tensor)
@@ -353,7 +353,7 @@ def test_nondistilled_devit_vs_oracle(dev):
     for name, p in m.named_parameters():
         g_ref = st_g[name].grad
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
-        assert chk(rel(p.grad, g_ref.numpy()), 8e-2), (name, rel(p.grad, g_ref.numpy()))
+        assert chk(rel(p.grad, g_ref.numpy()), 3e-2), (name, rel(p.grad, g_ref.numpy()))
 
 
 # ------------------------------------------------------------------------------------------ batch-size edges
@@ -370,7 +370,7 @@ def test_batch_invariance_and_ragged_batches(models, dev):
             assert torch.equal(s(img[lo:hi]), full_s[lo:hi]), (lo, hi)
             assert torch.equal(t(img[lo:hi]), full_t[lo:hi]), (lo, hi)
         ref = O.forward(st_s, GS, img[:1].cpu(), training=False)["output"]
-    assert chk(rel(full_s[:1], ref.numpy()), 3e-2)
+    assert chk(rel(full_s[:1], ref.numpy()), 2e-2)
     # a bs-3 training step (forward + backward) between two eval calls leaves the eval result untouched
     s.train()
     out = s(img[:3], output_qkv=True)
@@ -408,14 +408,14 @@ def test_step_other_class_counts(dev, classes):
     out["loss"].backward()
     for k in ("loss", "cls_loss", "q_loss", "k_loss", "v_loss"):
         assert abs(float(out[k].detach()) - float(ref[k].detach())) < 2e-2 * abs(float(ref[k].detach())) + 1e-6, k
-    assert chk(rel(out["logits"][0], ref["student"]["output"][0].detach().numpy()), 3e-2)
-    assert chk(rel(out["teacher_logits"], ref["teacher"]["output"].numpy()), 3e-2)
+    assert chk(rel(out["logits"][0], ref["student"]["output"][0].detach().numpy()), 2e-2)
+    assert chk(rel(out["teacher_logits"], ref["teacher"]["output"].numpy()), 2e-2)
     got = dict(s.named_parameters())
     for k in ("head.weight", "head_dist.weight", "head.bias", "blocks.11.mlp.fc2.weight", "blocks.0.attn.qkv.weight",
               "blocks.3.attn.qkv.bias", "blocks.7.mlp.fc1.bias",       # row sums fused into the weight-gradient GEMMs
               "blocks.7.mlp.fc2.bias", "blocks.2.attn.proj.bias",      # column sums fused into the LayerNorm backward
               "blocks.4.norm1.weight", "blocks.4.norm2.bias"):
-        assert chk(rel(got[k].grad, leaf[k].grad.numpy()), 6e-2), k
+        assert chk(rel(got[k].grad, leaf[k].grad.numpy()), 2.5e-2), k
 
 
 # ------------------------------------------------------------------------------------------ composite block calls

@@ -8,7 +8,7 @@ dev = torch.device("cuda"); B, C = 256, 25
 student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None).to(dev).train()
 teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
 for p in teacher.parameters(): p.requires_grad_(False)
-flat = ddp.FlatParams(student).attach_bf16(student); reducer = ddp.BucketedGradReducer(flat).attach(student)
+flat = ddp.FlatParams(student); flat.attach_bf16(student); reducer = ddp.BucketedGradReducer(flat).attach(student)
 opt = optim.FlatAdamW(flat, lr=1e-4, weight_decay=0.0, max_norm=1.0, ema_decay=0.99996)
 crit = losses.DistillLoss(losses.SoftTargetCrossEntropy(), "hard", 0.5, 1.0)
 img = torch.randn(B, 3, 224, 224, device=dev); soft = torch.softmax(torch.randn(B, C, device=dev), 1)
