@@ -167,6 +167,17 @@ def stub_main(args, rank, world, json_out):
     dist.destroy_process_group()
 
 
+def pmc_mfma_busy():
+    """MFMA-pipe busy fraction of the dominant template from the committed rocprofv3 counter pass over this same command
+    (tools/gpu_pmc_mfma.sh -> profiles/*_pmc_mfma.json).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_mfma.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("mfma_busy")
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -350,7 +361,7 @@ def main():
     fl, tm, cnt = by_t[dom]
     roof = {"bound": "mfma", "kernel": "gemm_kernel<*, A_row, B_row, *> (persistent 128x128 / 256x256 x64 bf16 MFMA tiles; fwd Linear layers of teacher + student)",
             "achieved": round(fl / tm / 1e12, 2), "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": round(fl / tm / BF16_DENSE_PEAK, 4), "traffic": pmc_traffic(),
+            "frac": round(fl / tm / BF16_DENSE_PEAK, 4), "traffic": pmc_traffic(), "mfma_busy": pmc_mfma_busy(),
             "launches_per_step": cnt, "avg_launch_us": round(tm / cnt * 1e6, 2),
             "gflop_per_launch_avg": round(fl / cnt / 1e9, 3),
             "step_frac": round(img_per_s / world * GFLOP_PER_IMG_STEP * 1e9 / BF16_DENSE_PEAK, 4),

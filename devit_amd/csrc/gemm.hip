@@ -17,6 +17,17 @@
 namespace {
 
 constexpr int BK = 64;
+// cache policy of the operand LDS-DMA (diagnostic switches; measured in DESIGN.md): nt = streaming / evict-first
+#ifdef DEVIT_DMA_A_NT
+constexpr bool DMA_A_NT = true;
+#else
+constexpr bool DMA_A_NT = false;
+#endif
+#ifdef DEVIT_DMA_B_NT
+constexpr bool DMA_B_NT = true;
+#else
+constexpr bool DMA_B_NT = false;
+#endif
 #ifndef DEVIT_RAGGED_MIN_K
 #define DEVIT_RAGGED_MIN_K 768
 #endif
@@ -98,8 +109,24 @@ __device__ __forceinline__ unsigned lane_offset(int ld, int wave, int lane, int 
 // safe because they can only be stricter with extra operations in the queue.  M0 (the DMA's LDS base) is saved and
 // restored around the statement; the padding covers SGPR-write -> VMEM-read and M0-write -> LDS-DMA wait states
 // (cdna_hip_programming.md §5.7).
+template <bool NT = false>
 __device__ __forceinline__ void dma2_uniform(const char* ubase, unsigned off0, unsigned off1, unsigned lds) {
   unsigned keep;
+  if (NT) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 2\n\t"
+        "global_load_lds_dwordx4 %3, %2 nt\n\t"
+        "s_add_u32 m0, %1, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %2 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds), "s"(ubase), "v"(off0), "v"(off1)
+        : "memory", "scc");
+    return;
+  }
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %1\n\t"
@@ -129,7 +156,7 @@ __device__ __forceinline__ void dma2_perlane(const void* p0, const void* p1, uns
       : "memory", "scc");
 }
 
-template <bool KM, int W, int NWAVES>
+template <bool KM, int W, int NWAVES, bool NT = false>
 __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, int group, int skip,
                                            char* lds_tile, int wave, int lane, int valid = W) {
   constexpr int CNT = (W / 8) / NWAVES;
@@ -154,8 +181,8 @@ __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, in
   const char* ubase = (const char*)org + (size_t)k0 * (KM ? (size_t)ld : (size_t)1) * 2;   // wave-uniform
 #pragma unroll
   for (int i = 0; i < CNT; i += 2)
-    dma2_uniform(ubase, lane_offset<KM, W, NWAVES>(ld, wave, lane, i, valid), lane_offset<KM, W, NWAVES>(ld, wave, lane, i + 1, valid),
-                 lds0 + i * 1024u);
+    dma2_uniform<NT>(ubase, lane_offset<KM, W, NWAVES>(ld, wave, lane, i, valid), lane_offset<KM, W, NWAVES>(ld, wave, lane, i + 1, valid),
+                     lds0 + i * 1024u);
 }
 
 // Offset, inside a 64-wide wave tile, of operand row p (0..15) of 16-row tile j.  PAIRED interleaves tiles 2q and
@@ -207,6 +234,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // change of the step time (the consumer kernels pay what the producers gain).
 template <typename T>
 __device__ __forceinline__ void st_out(T* p, T v) {
+#ifdef DEVIT_GEMM_NOSTORE   // diagnostic build: the epilogue computes everything and stores (almost) nothing
+  if (__builtin_expect(((size_t)p & 0xfffff0) == 0x7ffff0, 0))
+#endif
   *p = v;
 }
 
@@ -437,6 +467,9 @@ void gemm_kernel(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+#ifdef DEVIT_GEMM_TSTAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // this workgroup's tiles: first, first + stride, ... < last
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, stride = gridDim.x >> 3;
@@ -471,16 +504,16 @@ void gemm_kernel(const GemmArgs g) {
 #ifdef DEVIT_GEMM_NODMA       // diagnostic build: MFMAs + LDS reads alone (operands are whatever the LDS holds)
     if (g.K < 0)
 #endif
-    stage_tile<A_KM, BM, NWAVES>(c.ref.a, g.lda, (c.ref.kt0 + c.t) * BK, g.a_group, g.a_skip, smem + a_slot * A_TILE_BYTES,
-                                 wave, lane);
+    stage_tile<A_KM, BM, NWAVES, DMA_A_NT>(c.ref.a, g.lda, (c.ref.kt0 + c.t) * BK, g.a_group, g.a_skip,
+                                           smem + a_slot * A_TILE_BYTES, wave, lane);
     a_slot = a_slot + 1 == NA ? 0 : a_slot + 1;
   };
   auto dma_b = [&](const Cursor& c) {
 #ifdef DEVIT_GEMM_NODMA
     if (g.K < 0)
 #endif
-    stage_tile<B_KM, BN, NWAVES>(c.ref.b, g.ldb, (c.ref.kt0 + c.t) * BK, g.b_group, g.b_skip,
-                                 smem + B_RING + b_slot * B_TILE_BYTES, wave, lane, min(BN, g.N - c.ref.n0));
+    stage_tile<B_KM, BN, NWAVES, DMA_B_NT>(c.ref.b, g.ldb, (c.ref.kt0 + c.t) * BK, g.b_group, g.b_skip,
+                                           smem + B_RING + b_slot * B_TILE_BYTES, wave, lane, min(BN, g.N - c.ref.n0));
     b_slot ^= 1;
   };
   auto issue_a = [&]() {
@@ -531,6 +564,15 @@ void gemm_kernel(const GemmArgs g) {
     wait_vmcnt<0>();
     bar();
     int ca_slot = 0, cb_slot = 0;
+#ifdef DEVIT_GEMM_TSTAMP   // diagnostic build: per tile {K loop start, K loop end, epilogue end}, per K-step end of the 2nd tile
+    unsigned long long* tdbg = g.ep.pos ? (unsigned long long*)g.ep.pos + ((size_t)blockIdx.x * NWAVES + wave) * 48 : nullptr;
+    int tcount = 0;
+    if (tdbg && lane == 0) {
+      tdbg[40] = t_entry;
+      tdbg[42] = rt_entry;
+      tdbg[44] = __builtin_amdgcn_s_memtime();      // ring primed: first K loop can start
+    }
+#endif
     for (int tile = first; tile < last; tile += stride) {
       const TileRef ct = decode_tile<BM, BN, A_KM, B_KM>(g, tile);
       f32x4 acc[MI][NI];
@@ -540,8 +582,19 @@ void gemm_kernel(const GemmArgs g) {
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const devit_epilogue& ep = g.ep;
       const int nw = ct.n0 + wn * WN;
+#ifdef DEVIT_GEMM_TSTAMP
+      if (tdbg && lane == 0 && tcount < 8) tdbg[tcount * 3 + 0] = __builtin_amdgcn_s_memtime();
+#endif
       int noff[4];
       f32x4 bias[4], cs[4];
+#ifdef DEVIT_GEMM_STAMP    // diagnostic build: s_memtime at the edges of the four intervals of K-step 3 of the first tile
+      unsigned long long stamp[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) stamp[q] = 0;
+#define DEVIT_STAMP(q) do { if (t == 3 && tile == first) stamp[q] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DEVIT_STAMP(q) do { } while (0)
+#endif
       if (wm == 1) bar();              // the offset: this group now runs one interval behind
       for (int t = 0; t < ct.nk; ++t) {
         const char* cur_a = smem + ca_slot * A_TILE_BYTES;
@@ -553,21 +606,54 @@ void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           bf16x8 af[MI], bfr[NI];
+#ifdef DEVIT_GEMM_NOREAD     // diagnostic build: no fragment reads (operands are whatever the registers hold)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) asm volatile("" : "=v"(bfr[j]));
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" : "=v"(af[i]));
+#else
 #pragma unroll
           for (int j = 0; j < NI; ++j) bfr[j] = read_frag<B_KM, BN, PAIRED>(cur_b, wn * WN, j, kk, lane);
 #pragma unroll
           for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM, false>(cur_a, wm * WM, i, kk, lane);
+#endif
+          DEVIT_STAMP(kk * 6 + 0);     // fragment reads issued
           if (kk == 1) wait_stage();   // stage t+1 has landed; A of stage t+2 may stay in flight
+          DEVIT_STAMP(kk * 6 + 1);     // DMA wait over
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          DEVIT_STAMP(kk * 6 + 2);     // fragments in registers
           bar();
+          DEVIT_STAMP(kk * 6 + 3);     // through the barrier
+#ifdef DEVIT_GEMM_NOMFMA     // diagnostic build: fragment reads and barriers alone
+#pragma unroll
+          for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#else
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
+#endif
+          DEVIT_STAMP(kk * 6 + 4);     // MFMAs issued
           bar();
+          DEVIT_STAMP(kk * 6 + 5);     // through the barrier
         }
+#ifdef DEVIT_GEMM_TSTAMP
+        if (tdbg && lane == 0 && tcount == 1 && t < 16 && (g.M & 1)) tdbg[24 + t] = __builtin_amdgcn_s_memtime();
+#endif
       }
+#ifdef DEVIT_GEMM_TSTAMP
+      if (tdbg && lane == 0 && tcount < 8) tdbg[tcount * 3 + 1] = __builtin_amdgcn_s_memtime();
+#endif
       if (wm == 0) bar();              // pairs with the lagging group's last barrier: both groups run the epilogue
+#ifdef DEVIT_GEMM_STAMP
+      if (tile == first && lane == 0 && g.ep.pos != nullptr) {
+        unsigned long long* dbg = (unsigned long long*)g.ep.pos + ((size_t)blockIdx.x * NWAVES + wave) * 12;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) dbg[q] = stamp[q];
+      }
+#endif
       if (nw < g.N) {                  // (a wave whose 64 columns lie past a ragged N has nothing to store)
         settle_cols<KIND>(bias, cs);   // together (one after the other would double its MFMA-idle time)
         const size_t ob = (size_t)ct.bz * ep.out_batch_stride;
@@ -575,7 +661,18 @@ void gemm_kernel(const GemmArgs g) {
         if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
         else epilogue_direct<KIND, MI, false>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
       }
+#ifdef DEVIT_GEMM_TSTAMP
+      if (tdbg && lane == 0 && tcount < 8) tdbg[tcount * 3 + 2] = __builtin_amdgcn_s_memtime();
+      ++tcount;
+#endif
     }
+#ifdef DEVIT_GEMM_TSTAMP
+    if (tdbg && lane == 0) {
+      tdbg[41] = __builtin_amdgcn_s_memtime();
+      tdbg[43] = __builtin_amdgcn_s_memrealtime();
+      tdbg[45] = tcount;
+    }
+#endif
     return;
   }
 
