@@ -78,6 +78,8 @@ SIGNATURES = {
     "devit_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "devit_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "devit_im2row_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "devit_mix_im2row_bf16": (_I, [_P, _P, _I, _I, C.c_double, _I, _I, _I, _I, _P]),
+    "devit_mix_targets": (_I, [_P, _P, _I, _I, C.c_double, C.c_double, _P]),
     "devit_embed_tokens": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "devit_embed_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "devit_cast_bf16": (_I, [_P, _P, _Z, _P]),

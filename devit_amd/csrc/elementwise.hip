@@ -19,6 +19,62 @@ __global__ __launch_bounds__(256) void im2row_kernel(const float* img, __bf16* r
   }
 }
 
+// ---- Mixup / CutMix fused into im2row (engine.py:65-66 -> timm Mixup(mode='batch') -> patch_embed, de_vit.py:258) ---
+// rows[b] = patches of   mode 1: lam * img[b] + (1 - lam) * img[B-1-b]        (x.mul_(lam).add_(x.flip(0) * (1 - lam)))
+//                        mode 2: img[b] with the box [y0,y1) x [x0,x1) taken from img[B-1-b]   (x[:, :, yl:yh, xl:xh] = ...)
+//                        mode 0: img[b]
+// One read of the fp32 batch (each image twice), bf16 patch rows out; the mixed fp32 batch never exists.  The products
+// and the sum are rounded separately (no FMA contraction), as the reference's tensor ops round them.
+struct MixArgs {
+  const float* img;
+  __bf16* rows;
+  int B, mode, y0, y1, x0, x1;
+  float lam, oml;      // f32(lam), f32(1 - lam) with the subtraction done in double on the host, as torch does for a python scalar
+};
+__global__ __launch_bounds__(256) void mix_im2row_kernel(const MixArgs a) {
+  const int total = a.B * 196 * 96;
+  const float lam = a.lam, oml = a.oml;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int k8 = idx % 96, row = idx / 96;
+    const int b = row / 196, t = row % 196, py = t / 14, px = t % 14;
+    const int c = k8 >> 5, kh = (k8 >> 1) & 15, kw0 = (k8 & 1) * 8;
+    const int y = py * 16 + kh, x = px * 16 + kw0;
+    const size_t off = ((size_t)c * 224 + y) * 224 + x;
+    const float* src = a.img + (size_t)b * 3 * 224 * 224 + off;
+    const float* flp = a.img + (size_t)(a.B - 1 - b) * 3 * 224 * 224 + off;
+    float v[8];
+    *(f32x4*)v = *(const f32x4*)src;
+    *(f32x4*)(v + 4) = *(const f32x4*)(src + 4);
+    if (a.mode == 1) {
+      float w[8];
+      *(f32x4*)w = *(const f32x4*)flp;
+      *(f32x4*)(w + 4) = *(const f32x4*)(flp + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], lam), __fmul_rn(w[e], oml));
+    } else if (a.mode == 2 && y >= a.y0 && y < a.y1 && x + 8 > a.x0 && x < a.x1) {
+      float w[8];
+      *(f32x4*)w = *(const f32x4*)flp;
+      *(f32x4*)(w + 4) = *(const f32x4*)(flp + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (x + e >= a.x0 && x + e < a.x1) ? w[e] : v[e];
+    }
+    bf16x8 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]), f2bf(v[4]), f2bf(v[5]), f2bf(v[6]), f2bf(v[7])};
+    *(bf16x8*)(a.rows + (size_t)idx * 8) = o;
+  }
+}
+
+// targets[b][c] = lam * smooth(y[b])[c] + (1 - lam) * smooth(y[B-1-b])[c],  smooth(y)[c] = eps / C + (c == y) * (1 - eps)
+// (timm mixup_target / one_hot; distill_sub.py:315-318)
+__global__ __launch_bounds__(256) void mix_targets_kernel(const long long* y, float* out, int B, int C, float lam, float oml,
+                                                          float off, float on) {
+  const int total = B * C;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int b = idx / C, c = idx % C;
+    const float t1 = (int)y[b] == c ? on : off, t2 = (int)y[B - 1 - b] == c ? on : off;
+    out[idx] = __fadd_rn(__fmul_rn(t1, lam), __fmul_rn(t2, oml));
+  }
+}
+
 // ---- x[b, t] = token_t + pos[t] for the extra (cls / dist) tokens: models/de_vit.py:259-264 ----------
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const float* cls, const float* dist, const float* pos,
                                                            float* x, int B, int T, int D, int ntok) {
@@ -280,6 +336,28 @@ extern "C" int devit_im2row_bf16(const float* img, void* rows, int B, int C, int
               "devit_im2row_bf16: only 3x224x224 / patch 16 (got %dx%dx%d / %d)", C, H, W, patch);
   hipLaunchKernelGGL(im2row_kernel, dim3(grid_for((size_t)B * 196 * 96, 4096)), dim3(256), 0, (hipStream_t)stream, img,
                      (__bf16*)rows, B);
+  DEVIT_LAUNCH_CHECK();
+  return DEVIT_OK;
+}
+
+extern "C" int devit_mix_im2row_bf16(const float* img, void* rows, int B, int mode, double lam, int y0, int y1, int x0, int x1,
+                                     void* stream) {
+  DEVIT_CHECK(img && rows && B > 0, DEVIT_ERR_ARG, "devit_mix_im2row_bf16: bad argument");
+  DEVIT_CHECK(mode >= 0 && mode <= 2, DEVIT_ERR_ARG, "devit_mix_im2row_bf16: mode %d (0 none, 1 mixup, 2 cutmix)", mode);
+  DEVIT_CHECK(mode != 2 || (0 <= y0 && y0 <= y1 && y1 <= 224 && 0 <= x0 && x0 <= x1 && x1 <= 224), DEVIT_ERR_ARG,
+              "devit_mix_im2row_bf16: box [%d,%d) x [%d,%d) outside 224x224", y0, y1, x0, x1);
+  MixArgs a{img, (__bf16*)rows, B, mode, y0, y1, x0, x1, (float)lam, (float)(1.0 - lam)};
+  hipLaunchKernelGGL(mix_im2row_kernel, dim3(grid_for((size_t)B * 196 * 96, 4096)), dim3(256), 0, (hipStream_t)stream, a);
+  DEVIT_LAUNCH_CHECK();
+  return DEVIT_OK;
+}
+
+extern "C" int devit_mix_targets(const long long* labels, float* targets, int B, int C, double lam, double smoothing,
+                                 void* stream) {
+  DEVIT_CHECK(labels && targets && B > 0 && C > 0, DEVIT_ERR_ARG, "devit_mix_targets: bad argument");
+  const double off = smoothing / C, on = 1.0 - smoothing + off;      // timm mixup_target: off / on values in double
+  hipLaunchKernelGGL(mix_targets_kernel, dim3(grid_for((size_t)B * C)), dim3(256), 0, (hipStream_t)stream, labels, targets, B,
+                     C, (float)lam, (float)(1.0 - lam), (float)off, (float)on);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }

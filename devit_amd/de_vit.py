@@ -360,9 +360,11 @@ class VisionTransformer(nn.Module):
     # ---- forward --------------------------------------------------------------------------------------
     def embed(self, x):
         """patch_embed + cls/dist tokens + pos_embed (de_vit.py:258-264) -> fp32 [B, T, D]."""
-        L.require_device(x)
+        L.require_device(x.rows if isinstance(x, ops.PatchRows) else x)
         if self.precision == "f32":
             from . import ops_f32
+            if isinstance(x, ops.PatchRows):
+                raise L.DevitError('precision="f32" reads the fp32 images: pass the image tensor, not bf16 PatchRows')
             return ops_f32.PatchEmbedF32Fn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias,
                                                  self.cls_token, self.dist_token, self.pos_embed, self.grad_ready)
         return ops.PatchEmbedFn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token,

@@ -26,6 +26,11 @@ class MultiViT(nn.Module):
                 self.backbones[i].head_dist = nn.Identity()
 
     def forward(self, x):
+        # the backbones read the same batch: cut it into bf16 patch rows ONCE (the reference runs four patch-embedding
+        # convolutions over the same images, :33-39)
+        from . import ops
+        if x.is_cuda and all(getattr(m, "precision", "bf16") == "bf16" for m in self.backbones):
+            x = ops.patch_rows(x)
         feats = [m.forward_features(x) for m in self.backbones]
         if 'vit' in self.model:
             return [f['output'] for f in feats]

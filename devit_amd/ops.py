@@ -577,19 +577,67 @@ class EncoderFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # patch embedding + token assembly (models/de_vit.py:258-264)
 # ----------------------------------------------------------------------------------------------
+class PatchRows:
+    """A batch of images already cut into bf16 patch rows [pad_rows(B*196), 768] (k = c*256 + kh*16 + kw): what every
+    model's patch-embedding GEMM reads.  Models accept it in place of the fp32 image tensor, so one im2row pass -- plain
+    (`patch_rows`) or fused with Mixup / CutMix (`mix_patch_rows`) -- serves the student, the teacher and all MultiViT
+    backbones of a step.  Quacks like the image batch where host code only asks for its size and place."""
+
+    def __init__(self, rows, B):
+        self.rows, self.B = rows, B
+        self.shape = (B, 3, 224, 224)
+
+    is_cuda = property(lambda self: self.rows.is_cuda)
+    device = property(lambda self: self.rows.device)
+    dtype = torch.float32
+
+    def record_stream(self, s):
+        self.rows.record_stream(s)
+
+
+def patch_rows(img):
+    """fp32 [B,3,224,224] -> PatchRows (devit_im2row_bf16)."""
+    if isinstance(img, PatchRows):
+        return img
+    L.require_device(img)
+    img = img.contiguous().float()
+    B = img.shape[0]
+    rows = rows_alloc(B * 196, 768, BF16, img.device)
+    call("devit_im2row_bf16", ptr(img), ptr(rows), B, 3, 224, 224, 16, stream_ptr())
+    return PatchRows(rows, B)
+
+
+def mix_patch_rows(img, mode, lam=1.0, box=(0, 0, 0, 0)):
+    """Mixup (mode 1) / CutMix (mode 2, box = (y0, y1, x0, x1)) of a batch with its flip, straight to patch rows
+    (devit_mix_im2row_bf16; timm Mixup mode='batch', engine.py:65-66)."""
+    L.require_device(img)
+    img = img.contiguous().float()
+    B = img.shape[0]
+    rows = rows_alloc(B * 196, 768, BF16, img.device)
+    call("devit_mix_im2row_bf16", ptr(img), ptr(rows), B, int(mode), float(lam), int(box[0]), int(box[1]), int(box[2]),
+         int(box[3]), stream_ptr())
+    return PatchRows(rows, B)
+
+
+def mix_targets(labels, num_classes, lam, smoothing):
+    """[B, C] soft targets of the mixed batch (timm mixup_target)."""
+    L.require_device(labels)
+    labels = labels.contiguous().long()
+    out = torch.empty((labels.shape[0], num_classes), dtype=F32, device=labels.device)
+    call("devit_mix_targets", ptr(labels), ptr(out), labels.shape[0], num_classes, float(lam), float(smoothing), stream_ptr())
+    return out
+
+
 class PatchEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, proj_w, proj_b, cls_token, dist_token, pos_embed, w16, grad_ready):
-        L.require_device(img)
-        img = img.contiguous().float()
-        B = img.shape[0]
+        pre = img if isinstance(img, PatchRows) else patch_rows(img)
+        rows, B, dev = pre.rows, pre.B, pre.rows.device
         D = proj_w.shape[0]
         ntok = 2 if dist_token is not None else 1
         T = 196 + ntok
         M = B * 196
-        rows = rows_alloc(M, 768, BF16, img.device)
-        call("devit_im2row_bf16", ptr(img), ptr(rows), B, 3, 224, 224, 16, stream_ptr())
-        x = torch.empty((B, T, D), dtype=F32, device=img.device)
+        x = torch.empty((B, T, D), dtype=F32, device=dev)
         gemm(rows, 768, 0, w16, 768, 0, pad_rows(M), D, 768, kind=L.EPI_PATCH_F32, out=x, ldc=D, bias=proj_b,
              pos=pos_embed, patch_tokens=196, extra_tokens=ntok, m_valid=M)
         call("devit_embed_tokens", ptr(cls_token), ptr(dist_token), ptr(pos_embed), ptr(x), B, T, D, stream_ptr())

@@ -22,7 +22,7 @@ import torch
 from . import ops
 
 __all__ = ["compact", "uncompact", "compact_block_weights", "compacted_gflops", "masks_from_sparsity", "load_policy",
-           "get_policy", "save_gates", "load_gates", "read_shrink_checkpoint", "rank_units", "apply_shrink"]
+           "get_policy", "save_gates", "load_gates", "read_shrink_checkpoint", "rank_units", "apply_shrink", "neuron_scores", "head_scores"]
 
 
 def _round_up(n, m):
@@ -195,12 +195,36 @@ def _hsic(x, y, y_kernel, mean_sub):
 
 
 @torch.no_grad()
+def neuron_scores(neuron_output, prob):
+    """core/imp_rank.py:31-41 for one Mlp: 0.1 * min-max(HSIC(activation of neuron j over [B, N], softmax(logits))) +
+    0.9 * min-max(sum |activation|).  neuron_output [B, N, hidden], prob [B, C] -> [hidden]."""
+    X = neuron_output.float()
+    hs = _hsic(X.permute(2, 0, 1), prob, 'linear', True)
+    hs = (hs - hs.min()) / (hs.max() - hs.min())
+    act = X.abs().sum((0, 1))
+    act = (act - act.min()) / (act.max() - act.min())
+    return 0.1 * hs + 0.9 * act
+
+
+@torch.no_grad()
+def head_scores(head_output, prob):
+    """core/imp_rank.py:108-123 for one Attention: relevance(head) - 0.1 * mean redundancy against the other heads, on
+    the head's channel mean.  head_output [B, N, H, hd], prob [B, C] -> [H]."""
+    Hh = head_output.float().mean(-1).permute(2, 0, 1)              # [H, B, N]
+    relv = _hsic(Hh, prob, 'linear', True)
+    nH = Hh.shape[0]
+    red = torch.stack([sum(_hsic(Hh[a], Hh[b], 'rbf', False) for b in range(nH) if b != a) / (nH - 1) for a in range(nH)])
+    return relv - 0.1 * red
+
+
+@torch.no_grad()
 def rank_units(model, data_loader, device=None):
     """One-batch importance ranking of every block's MLP neurons and attention heads (core/imp_rank.py:16-47 and
-    :93-129): neurons by 0.1 * HSIC(activation, softmax(logits)) + 0.9 * |activation| mass, both min-max normalised;
-    heads by relevance - 0.1 * mean redundancy against the other heads.  Reads the `neuron_output` / `head_output` the
-    forward leaves on the modules (post-gate values).  Returns (neuron_rank, head_rank): per block an
-    ascending argsort (numpy), the input of masks_from_sparsity.  Host-side torch arithmetic: a one-off setup step."""
+    :93-129).  Reads the `neuron_output` / `head_output` the forward leaves on the modules (post-gate values, SURVEY
+    App. D Q3).  Returns (neuron_rank, head_rank): per block an ascending argsort (numpy), the input of
+    masks_from_sparsity.  The reference calls the model in whatever mode it is in (train at that point of
+    distill_sub.py, where a distilled model returns a tuple that F.softmax cannot take); here: eval mode, averaged heads.
+    Host-side torch arithmetic on a single batch: a one-off setup step, not the hot path."""
     import numpy as np
     data, _ = next(iter(data_loader))
     if device is not None:
@@ -212,17 +236,8 @@ def rank_units(model, data_loader, device=None):
     prob = torch.softmax(out.float(), dim=-1)
     neuron_rank, head_rank = [], []
     for blk in _blocks(model):
-        X = blk.mlp.neuron_output.float()                           # [B, N, hidden]
-        hs = _hsic(X.permute(2, 0, 1), prob, 'linear', True)        # one HSIC per neuron over [B, N] features
-        hs = (hs - hs.min()) / (hs.max() - hs.min())
-        act = X.abs().sum((0, 1))
-        act = (act - act.min()) / (act.max() - act.min())
-        neuron_rank.append(np.argsort((0.1 * hs + 0.9 * act).cpu().numpy()))
-        Hh = blk.attn.head_output.float().mean(-1).permute(2, 0, 1)  # [H, B, N]: mean over the head's 64 channels
-        relv = _hsic(Hh, prob, 'linear', True)
-        nH = Hh.shape[0]
-        red = torch.stack([sum(_hsic(Hh[a], Hh[b], 'rbf', False) for b in range(nH) if b != a) / (nH - 1) for a in range(nH)])
-        head_rank.append(np.argsort((relv - 0.1 * red).cpu().numpy()))
+        neuron_rank.append(np.argsort(neuron_scores(blk.mlp.neuron_output, prob).cpu().numpy()))
+        head_rank.append(np.argsort(head_scores(blk.attn.head_output, prob).cpu().numpy()))
     model.train(was_training)
     return neuron_rank, head_rank
 

@@ -95,29 +95,32 @@ class SyntheticLoader:
 
 
 class Mixup:
-    """timm.data.Mixup(mode='batch') semantics as device tensor ops."""
+    """timm.data.Mixup(mode='batch') semantics (distill_sub.py:315-318, applied at engine.py:65-66).
+    The draws (mixup vs cutmix, lambda ~ Beta, the box) are host-side numpy RNG as in timm; the arithmetic runs in two HIP
+    kernels: devit_mix_im2row_bf16 turns the fp32 batch straight into the MIXED batch's bf16 patch rows (the mixed fp32
+    images never exist; student and teacher both read those rows) and devit_mix_targets builds the soft targets."""
 
     def __init__(self, mixup_alpha, cutmix_alpha, prob, switch_prob, label_smoothing, num_classes):
         self.ma, self.ca, self.prob, self.sw, self.eps, self.C = mixup_alpha, cutmix_alpha, prob, switch_prob, label_smoothing, num_classes
 
-    def __call__(self, x, y):
-        assert x.shape[0] % 2 == 0, 'Batch size should be even when using this'
+    def draw(self, H=224, W=224):
+        """(mode, lam, box): mode 0 none / 1 mixup / 2 cutmix; lam already corrected to the clipped box area for cutmix."""
         lam, cut = 1.0, False
         if np.random.rand() < self.prob:
             cut = self.ca > 0 and (self.ma <= 0 or np.random.rand() < self.sw)
             lam = float(np.random.beta(self.ca, self.ca) if cut else np.random.beta(self.ma, self.ma))
         if cut:
-            H, W = x.shape[-2:]
             r = math.sqrt(1 - lam)
             ch, cw, cy, cx = int(H * r), int(W * r), np.random.randint(H), np.random.randint(W)
             y0, y1, x0, x1 = max(cy - ch // 2, 0), min(cy + ch // 2, H), max(cx - cw // 2, 0), min(cx + cw // 2, W)
-            x[:, :, y0:y1, x0:x1] = x.flip(0)[:, :, y0:y1, x0:x1]
-            lam = 1.0 - (y1 - y0) * (x1 - x0) / float(H * W)
-        elif lam != 1.0:
-            x = x * lam + x.flip(0) * (1 - lam)
-        off, on = self.eps / self.C, 1 - self.eps + self.eps / self.C
-        oh = torch.full((y.shape[0], self.C), off, device=x.device).scatter_(1, y[:, None], on)
-        return x, oh * lam + oh.flip(0) * (1 - lam)
+            return 2, 1.0 - (y1 - y0) * (x1 - x0) / float(H * W), (y0, y1, x0, x1)
+        return (1 if lam != 1.0 else 0), lam, (0, 0, 0, 0)
+
+    def __call__(self, x, y):
+        from devit_amd import ops
+        assert x.shape[0] % 2 == 0, 'Batch size should be even when using this'
+        mode, lam, box = self.draw(x.shape[-2], x.shape[-1])
+        return ops.mix_patch_rows(x, mode, lam, box), ops.mix_targets(y, self.C, lam, self.eps)
 
 
 class CosineEpochs:

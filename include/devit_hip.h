@@ -220,6 +220,14 @@ int devit_block_bwd(const devit_block_weights* w, const devit_block_acts* acts, 
  *   dx_bf16 (optional) = bf16 copy of dx for the patch-projection wgrad.
  * ---------------------------------------------------------------------------------------- */
 int devit_im2row_bf16(const float* img, void* rows, int B, int C, int H, int W, int patch, void* stream);
+/* On-device input stage (engine.py:65-66: timm Mixup(mode='batch') on the fp32 batch, then patch_embed): the mixed batch is
+ * produced directly as the bf16 patch rows both models' patch-embedding GEMMs read -- one pass over the images.
+ *   mode 0: plain im2row; 1: mixup  lam * x + (1 - lam) * x.flip(0);  2: cutmix  x[:, :, y0:y1, x0:x1] = x.flip(0)[...]
+ *   (lam, the box and the mixup / cutmix draw are host-side numpy RNG in timm; they are arguments here).
+ * devit_mix_targets: [B][C] f32 = lam * smooth_one_hot(y) + (1 - lam) * smooth_one_hot(y.flip(0)), int64 labels. */
+int devit_mix_im2row_bf16(const float* img, void* rows, int B, int mode, double lam, int y0, int y1, int x0, int x1,
+                          void* stream);
+int devit_mix_targets(const long long* labels, float* targets, int B, int C, double lam, double smoothing, void* stream);
 int devit_embed_tokens(const float* cls, const float* dist, const float* pos, float* x, int B, int T, int D,
                        void* stream);
 int devit_embed_bwd(const float* dx, int B, int T, int D, int ntok, float* dpos, float* dcls, float* ddist,

@@ -187,6 +187,113 @@ def make_ensemble(create_model, de_vit, ref_losses):
          g_b0_pos=multi.backbones[0].pos_embed.grad[0, ::16], n_multi_keys=np.array(len(keys)))
 
 
+
+def make_misc(ref_losses):
+    """Round-2 fixtures: FLOP / parameter known answers (core/compute_metric.py), DeiT DistillationLoss
+    (utils/losses.py:44-119) with every base criterion train_subdata.py:409-416 can pick, the importance ranking of
+    core/imp_rank.py:16-47,93-129 on small synthetic activations, and Mixup / CutMix images + targets from timm's
+    formulas (timm is not installed: lambda and the box are inputs, so no RNG parity is involved)."""
+    spec = importlib.util.spec_from_file_location("_ref_metric", f"{REF}/core/compute_metric.py")
+    cm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cm)
+    z = [0.0] * 12
+    s = dict(emb=384, seq_length=197, mlp_ratio=4, head=6, layer=12, num_class=1000)
+    flops = {
+        "dedeit_dense_gflops": cm.cal_shrink_flops(z, z, **s), "dedeit_dense_mparams": cm.cal_shrink_paras(z, z, **s),
+        "deitb_dense_gflops": cm.cal_shrink_flops(z, z), "deitb_dense_mparams": cm.cal_shrink_paras(z, z),
+        "dedeit_shrunk_0.3_gflops": cm.cal_shrink_flops([0.3] * 12, [0.3] * 12, **s),
+        "dedeit_shrunk_0.3_mparams": cm.cal_shrink_paras([0.3] * 12, [0.3] * 12, **s),
+        "dedeit_c25_n198_gflops": cm.cal_shrink_flops(z, z, **{**s, "seq_length": 198, "num_class": 25}),
+        "deitb_c25_n198_gflops": cm.cal_shrink_flops(z, z, seq_length=198, num_class=25),
+        "dedeit_mixed_gflops": cm.cal_shrink_flops([0.1 * (i % 4) for i in range(12)], [0.17 * (i % 3) for i in range(12)], **s),
+    }
+    with open(os.path.join(HERE, "flops.json"), "w") as f:
+        json.dump(flops, f, indent=0)
+    print("flops.json", flops)
+
+    # ---- DistillationLoss (teacher inside the criterion) ------------------------------------------
+    B, C = 8, 25
+    lo = torch.from_numpy(det_array("dl/lo", (B, C), std=1.5)).requires_grad_(True)
+    lk = torch.from_numpy(det_array("dl/lk", (B, C), std=1.5)).requires_grad_(True)
+    lt = torch.from_numpy(det_array("dl/lt", (B, C), std=2.0))
+    y = torch.from_numpy(det_labels("dl/y", B, C))
+    soft = torch.softmax(torch.from_numpy(det_array("dl/soft", (B, C), std=2.0)), 1)
+
+    class Teacher(nn.Module):
+        def forward(self, x, *a):
+            return lt
+    out = dict(lo=lo, lk=lk, lt=lt, y=y, soft=soft)
+    bases = {"ce": (nn.CrossEntropyLoss(), y), "ls": (ref_losses.LabelSmoothingCrossEntropy(0.1), y),
+             "soft": (sys.modules["timm.loss"].SoftTargetCrossEntropy(), soft)}
+    for bname, (base, labels) in bases.items():
+        for kind, tau in (("none", 1.0), ("hard", 1.0), ("soft", 3.0)):
+            crit = ref_losses.DistillationLoss(base, Teacher(), kind, 0.5, tau, False)
+            loss = crit(torch.zeros(B, 3, 8, 8), (lo, lk), labels)
+            g = torch.autograd.grad(loss, [lo, lk], allow_unused=True)
+            out[f"{bname}_{kind}_loss"] = loss
+            out[f"{bname}_{kind}_dlo"] = g[0]
+            out[f"{bname}_{kind}_dlk"] = g[1] if g[1] is not None else torch.zeros_like(lk)
+    save("distillation_loss", **out)
+
+    # ---- importance ranking (core/imp_rank.py) on synthetic activations --------------------------
+    spec = importlib.util.spec_from_file_location("_ref_rank", f"{REF}/core/imp_rank.py")
+    ir = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ir)
+    nn.Module.cuda = lambda self, *a, **k: self          # the reference hard-codes .cuda() (imp_rank.py:17-18,26)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    Bn, Nn, Hid, H, hd, Cn = 6, 20, 48, 4, 8, 10
+
+    class Mlp(nn.Module):                                 # discovered by `'Mlp' in str(m)` (imp_rank.py:30)
+        def __init__(self, i):
+            super().__init__()
+            self.neuron_output = torch.from_numpy(det_array(f"rank/n{i}", (Bn, Nn, Hid), std=0.8))
+            self.hidden_features = Hid
+
+    class Attention(nn.Module):
+        def __init__(self, i):
+            super().__init__()
+            self.head_output = torch.from_numpy(det_array(f"rank/h{i}", (Bn, Nn, H, hd), std=0.8))
+            self.num_heads = H
+
+    class Fake(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a0, self.m0, self.a1, self.m1 = Attention(0), Mlp(0), Attention(1), Mlp(1)
+            self.logits = torch.from_numpy(det_array("rank/logits", (Bn, Cn), std=1.5))
+
+        def forward(self, x):
+            return self.logits
+    fake = Fake()
+    loader = [(torch.zeros(Bn, 3, 4, 4), torch.zeros(Bn, dtype=torch.long))]
+    nrank = ir.mlp_neuron_rank(fake, loader)
+    hrank = ir.attn_head_rank(fake, loader)
+    nmask = ir.mlp_neuron_mask(fake, [0.3, 0.5], nrank)
+    hmask = ir.attn_head_mask(fake, [0.3, 0.5], hrank)
+    save("imp_rank", logits=fake.logits, n0=fake.m0.neuron_output, n1=fake.m1.neuron_output, h0=fake.a0.head_output,
+         h1=fake.a1.head_output, neuron_rank=np.stack(nrank), head_rank=np.stack(hrank),
+         neuron_mask=torch.stack(nmask), head_mask=torch.stack(hmask), sparsity=np.array([0.3, 0.5]))
+
+    # ---- Mixup / CutMix (timm.data.Mixup, mode='batch'; SURVEY App. B) ---------------------------
+    Bm, Cm, eps = 4, 10, 0.1
+    img = det_array("mix/img", (Bm, 3, 224, 224))
+    yy = det_labels("mix/y", Bm, Cm)
+    off, on = eps / Cm, 1 - eps + eps / Cm
+    oh = np.full((Bm, Cm), off, np.float32)
+    oh[np.arange(Bm), yy] = on
+    lam = 0.37
+    mix_img = img * lam + img[::-1] * (1 - lam)
+    mix_t = oh * lam + oh[::-1] * (1 - lam)
+    y0, y1, x0, x1 = 30, 141, 64, 200
+    cut_img = img.copy()
+    cut_img[:, :, y0:y1, x0:x1] = img[::-1][:, :, y0:y1, x0:x1]
+    lam_c = 1.0 - (y1 - y0) * (x1 - x0) / float(224 * 224)
+    cut_t = oh * lam_c + oh[::-1] * (1 - lam_c)
+    sub = lambda a: a[:, :, ::7, ::5]                     # keeps the fixture small; the box edges fall between samples
+    save("mixup", y=yy, lam=np.float32(lam), box=np.array([y0, y1, x0, x1]), lam_cut=np.float32(lam_c), smoothing=np.float32(eps),
+         mix_img=sub(mix_img), mix_targets=mix_t, cut_img=sub(cut_img), cut_targets=cut_t,
+         cut_rows=cut_img[:, :, 28:32, 60:68], cut_rows2=cut_img[:, :, 139:143, 196:204])
+
+
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(0)
@@ -195,6 +302,9 @@ def main():
     import utils.losses as ref_losses       # noqa: E402  (reference)
     if "--only-ensemble" in sys.argv:
         make_ensemble(create_model, de_vit, ref_losses)
+        return
+    if "--only-misc" in sys.argv:
+        make_misc(ref_losses)
         return
 
     C = 25
@@ -348,6 +458,7 @@ def main():
     with open(os.path.join(HERE, "step_param_names.json"), "w") as f:
         json.dump(names, f)
     make_ensemble(create_model, de_vit, ref_losses)
+    make_misc(ref_losses)
     print("done")
 
 

@@ -3,6 +3,7 @@ the same op on the same (bf16-rounded) inputs.  Tolerances are stated per test: 
 fp32, so differences are summation-order noise plus one bf16 rounding of the stored output."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -435,3 +436,55 @@ def test_comm_rccl_single_rank(dev):
         comm.all_reduce(y.double())
     comm.destroy()
     comm.destroy()            # idempotent
+
+
+# ------------------------------------------------------------------------------------------ on-device input stage
+def _unrow(rows, B):
+    """bf16 patch rows [B*196, 768] -> image layout [B, 3, 224, 224]."""
+    return rows[: B * 196].view(B, 14, 14, 3, 16, 16).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
+
+
+def test_mixup_cutmix_im2row_and_targets(dev, golden):
+    """devit_mix_im2row_bf16 / devit_mix_targets against timm's Mixup(mode='batch') formulas evaluated by
+    tests/golden/make_golden.py (mixup.npz; lambda and the box are inputs): the mixed batch, as bf16 patch rows, equals
+    bf16(formula) -- bit for bit, one rounding; CutMix is an exact copy inside the box; mode 0 is plain im2row."""
+    from oracle.detgen import det_array, det_labels
+    from devit_amd import ops
+    g = golden("mixup")
+    B, C = 4, 10
+    img = torch.from_numpy(det_array("mix/img", (B, 3, 224, 224))).to(dev)
+    y = torch.from_numpy(det_labels("mix/y", B, C)).to(dev)
+    assert np.array_equal(y.cpu().numpy(), g["y"])
+    sub = lambda a: a[:, :, ::7, ::5]
+    lam, box = float(g["lam"]), [int(v) for v in g["box"]]
+    mixed = _unrow(ops.mix_patch_rows(img, 1, lam).rows, B)
+    assert torch.equal(sub(mixed).float().cpu(), torch.from_numpy(g["mix_img"]).to(BF16).float())
+    cut = _unrow(ops.mix_patch_rows(img, 2, 1.0, box).rows, B)
+    assert torch.equal(sub(cut).float().cpu(), torch.from_numpy(g["cut_img"]).to(BF16).float())
+    for key, (ys, xs) in (("cut_rows", (slice(28, 32), slice(60, 68))), ("cut_rows2", (slice(139, 143), slice(196, 204)))):
+        assert torch.equal(cut[:, :, ys, xs].float().cpu(), torch.from_numpy(g[key]).to(BF16).float())   # the box edges
+    full_ref = img.clone()
+    full_ref[:, :, box[0]:box[1], box[2]:box[3]] = img.flip(0)[:, :, box[0]:box[1], box[2]:box[3]]
+    assert torch.equal(cut, full_ref.to(BF16))                                       # every pixel, not only the samples
+    assert torch.equal(mixed, (img * lam + img.flip(0) * (1 - lam)).to(BF16))
+    plain = ops.mix_patch_rows(img, 0)
+    assert torch.equal(plain.rows, ops.patch_rows(img).rows)
+    t_mix = ops.mix_targets(y, C, lam, float(g["smoothing"]))
+    t_cut = ops.mix_targets(y, C, float(g["lam_cut"]), float(g["smoothing"]))
+    assert relerr(t_mix, torch.from_numpy(g["mix_targets"]).to(dev)) < 1e-6
+    assert relerr(t_cut, torch.from_numpy(g["cut_targets"]).to(dev)) < 1e-6
+    assert float((t_mix.sum(1) - 1).abs().max()) < 1e-6
+
+
+def test_models_take_patch_rows(dev):
+    """A model fed ops.PatchRows (one im2row pass shared by student, teacher and MultiViT backbones) gives the bits of the
+    same model fed the fp32 images."""
+    import devit_amd
+    from devit_amd import ops
+    torch.manual_seed(4)
+    m = devit_amd.create_model("dedeit", num_classes=10).to(dev).eval()
+    img = rnd((3, 3, 224, 224), dev, seed=9)
+    with torch.no_grad():
+        a = m(img)
+        b = m(ops.patch_rows(img))
+    assert torch.equal(a, b)

@@ -456,3 +456,34 @@ def test_block_calls_match_granular_path(models, dev, bs):
     assert torch.equal(lo0, lo1) and torch.equal(tl0, tl1) and torch.equal(l0, l1)
     for n in g0:
         assert chk(rel(g1[n], g0[n].cpu().numpy()), 2e-5), n          # split-K atomics: summation order only
+
+
+# ------------------------------------------------------------------------------------------ DeiT criterion of train_subdata.py
+def test_distillation_loss_vs_golden(golden, dev):
+    """losses.DistillationLoss against the reference's own class (utils/losses.py:44-119, teacher inside the criterion)
+    for every base criterion train_subdata.py:409-416 can select -- CrossEntropyLoss, LabelSmoothingCrossEntropy(0.1),
+    SoftTargetCrossEntropy -- times none / hard / soft(tau = 3): loss and both logit gradients, fp32 kernel."""
+    from devit_amd import losses
+    g = golden("distillation_loss")
+    lt = torch.from_numpy(g["lt"]).to(dev)
+
+    class Teacher(torch.nn.Module):
+        def forward(self, x, *a):
+            return lt
+    y, soft = torch.from_numpy(g["y"]).to(dev), torch.from_numpy(g["soft"]).to(dev)
+    bases = {"ce": (torch.nn.CrossEntropyLoss(), y), "ls": (losses.LabelSmoothingCrossEntropy(0.1), y),
+             "soft": (losses.SoftTargetCrossEntropy(), soft)}
+    for bname, (base, labels) in bases.items():
+        for kind, tau in (("none", 1.0), ("hard", 1.0), ("soft", 3.0)):
+            lo = torch.from_numpy(g["lo"]).to(dev).requires_grad_(True)
+            lk = torch.from_numpy(g["lk"]).to(dev).requires_grad_(True)
+            crit = losses.DistillationLoss(base, Teacher(), kind, 0.5, tau, False)
+            loss = crit(inputs=torch.zeros(8, 3, 8, 8, device=dev), outputs=(lo, lk), labels=labels)
+            dlo, dlk = torch.autograd.grad(loss, [lo, lk], allow_unused=True)
+            ref = float(g[f"{bname}_{kind}_loss"])
+            assert chk(abs(float(loss) - ref) / abs(ref), 1e-5), (bname, kind, float(loss), ref)
+            assert chk(rel(dlo, g[f"{bname}_{kind}_dlo"]), 1e-5), (bname, kind)
+            if kind != "none":
+                assert chk(rel(dlk, g[f"{bname}_{kind}_dlk"]), 1e-5), (bname, kind)
+            else:
+                assert dlk is None or float(dlk.abs().max()) == 0.0

@@ -8,6 +8,8 @@ import torch
 import devit_amd
 from devit_amd import de_vit, ddp, ops, registry
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -179,3 +181,59 @@ def test_gate_persistence_roundtrip(tmp_path):
     shrink.load_gates(holder, tmp_path / "gates.pt")
     assert torch.equal(blk.attn.gate, hm) and torch.equal(blk.mlp.gate, nm)
     assert "gate" not in "".join(holder.state_dict().keys())          # checkpoint ABI unchanged
+
+
+# ------------------------------------------------------------------------------------------ round-2 known answers
+def test_flop_accounting_matches_reference_formulas():
+    """core/compute_metric.py:1-69 evaluated by tests/golden/make_golden.py (flops.json): the build's accounting
+    (devit_amd.flops, used by bench.py's roofline and BASELINE.md section 2) reproduces it to the last digit."""
+    import json
+    import bench
+    from devit_amd import flops as F
+    g = json.load(open(os.path.join(GOLDEN, "flops.json")))
+    s = dict(emb=384, seq_length=197, mlp_ratio=4, head=6, layer=12, num_class=1000)
+    assert F.forward_gflops(**s) == g["dedeit_dense_gflops"] == 9.197764608
+    assert F.params_m(**s) == g["dedeit_dense_mparams"] == 22.03684
+    assert F.forward_gflops() == g["deitb_dense_gflops"] == 35.127656448 and F.params_m() == g["deitb_dense_mparams"]
+    assert F.forward_gflops(**s, neuron_sparsity=[0.3] * 12, head_sparsity=[0.3] * 12) == g["dedeit_shrunk_0.3_gflops"]
+    assert F.params_m(**s, neuron_sparsity=[0.3] * 12, head_sparsity=[0.3] * 12) == g["dedeit_shrunk_0.3_mparams"]
+    mixed = dict(neuron_sparsity=[0.1 * (i % 4) for i in range(12)], head_sparsity=[0.17 * (i % 3) for i in range(12)])
+    assert F.forward_gflops(**s, **mixed) == g["dedeit_mixed_gflops"]
+    assert F.macs_g(**s) == g["dedeit_dense_gflops"] / 2
+    # the benchmark's geometry (198 tokens, 25 classes) and the constant bench.py prices the step with
+    assert F.forward_gflops(**{**s, "seq_length": 198, "num_class": 25}) == g["dedeit_c25_n198_gflops"]
+    assert F.forward_gflops(seq_length=198, num_class=25) == g["deitb_c25_n198_gflops"]
+    assert abs(F.step_gflops_per_image() - bench.GFLOP_PER_IMG_STEP) < 1e-3 and abs(bench.GFLOP_PER_IMG_STEP - 63.503) < 1e-9
+    # physically shrunk models: the run sizes are padded to kernel granules (heads even, hidden % 128), so the FLOPs that
+    # actually run sit between the analytic shrunk cost and the dense one
+    import devit_amd
+    from devit_amd import shrink
+    m = devit_amd.create_model("dedeit", num_classes=1000)
+    dense = shrink.compacted_gflops(m, tokens=197)
+    assert abs(dense - g["dedeit_dense_gflops"]) < 0.01 * dense          # second head + exact conv vs the formula's 2*3*emb*224^2
+
+
+def test_importance_ranking_matches_reference():
+    """shrink.neuron_scores / head_scores / masks_from_sparsity against core/imp_rank.py's own mlp_neuron_rank,
+    attn_head_rank, mlp_neuron_mask, attn_head_mask run on synthetic activations (tests/golden/imp_rank.npz)."""
+    import numpy as np
+    from devit_amd import shrink
+    g = dict(np.load(os.path.join(GOLDEN, "imp_rank.npz")))
+    prob = torch.softmax(torch.from_numpy(g["logits"]), -1)
+    for i in range(2):
+        nr = np.argsort(shrink.neuron_scores(torch.from_numpy(g[f"n{i}"]), prob).numpy())
+        hr = np.argsort(shrink.head_scores(torch.from_numpy(g[f"h{i}"]), prob).numpy())
+        assert np.array_equal(nr, g["neuron_rank"][i]) and np.array_equal(hr, g["head_rank"][i])
+
+    class Blk:           # the two attributes masks_from_sparsity reads
+        def __init__(self, H, hid):
+            self.attn = type("A", (), {"num_heads": H})()
+            self.mlp = type("M", (), {"hidden_features": hid})()
+    real = shrink._blocks
+    shrink._blocks = lambda model: model
+    try:
+        pol = shrink.masks_from_sparsity([Blk(4, 48), Blk(4, 48)], g["sparsity"], g["sparsity"], g["neuron_rank"], g["head_rank"])
+    finally:
+        shrink._blocks = real
+    for i, (hm, nm) in enumerate(pol):
+        assert np.array_equal(hm.numpy(), g["head_mask"][i]) and np.array_equal(nm.numpy(), g["neuron_mask"][i])
