@@ -32,6 +32,7 @@ struct MixArgs {
   float lam, oml;      // f32(lam), f32(1 - lam) with the subtraction done in double on the host, as torch does for a python scalar
 };
 __global__ __launch_bounds__(256) void mix_im2row_kernel(const MixArgs a) {
+#pragma clang fp contract(off)   // x * lam + flip * (1 - lam) as three rounded operations (hipcc would fuse a multiply-add)
   const int total = a.B * 196 * 96;
   const float lam = a.lam, oml = a.oml;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(256) void mix_im2row_kernel(const MixArgs a) {
       *(f32x4*)w = *(const f32x4*)flp;
       *(f32x4*)(w + 4) = *(const f32x4*)(flp + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], lam), __fmul_rn(w[e], oml));
+      for (int e = 0; e < 8; ++e) {
+        const float p0 = v[e] * lam, p1 = w[e] * oml;
+        v[e] = p0 + p1;
+      }
     } else if (a.mode == 2 && y >= a.y0 && y < a.y1 && x + 8 > a.x0 && x < a.x1) {
       float w[8];
       *(f32x4*)w = *(const f32x4*)flp;
@@ -67,11 +71,13 @@ __global__ __launch_bounds__(256) void mix_im2row_kernel(const MixArgs a) {
 // (timm mixup_target / one_hot; distill_sub.py:315-318)
 __global__ __launch_bounds__(256) void mix_targets_kernel(const long long* y, float* out, int B, int C, float lam, float oml,
                                                           float off, float on) {
+#pragma clang fp contract(off)
   const int total = B * C;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int b = idx / C, c = idx % C;
     const float t1 = (int)y[b] == c ? on : off, t2 = (int)y[B - 1 - b] == c ? on : off;
-    out[idx] = __fadd_rn(__fmul_rn(t1, lam), __fmul_rn(t2, oml));
+    const float p0 = t1 * lam, p1 = t2 * oml;
+    out[idx] = p0 + p1;
   }
 }
 

@@ -17,6 +17,15 @@
 namespace {
 
 constexpr int BK = 64;
+#ifndef DEVIT_PP_SPREAD
+#define DEVIT_PP_SPREAD 0        // ping-pong schedule: LDS-DMA issue spread over all four intervals of a K-step (measured: -10 %)
+#endif
+#ifndef DEVIT_PP_SPLIT
+#define DEVIT_PP_SPLIT 1         // ping-pong schedule: B(t+1) issued in the first read interval, A(t+2) in the second
+#endif
+#ifndef DEVIT_PP_MFMA_AT
+#define DEVIT_PP_MFMA_AT 1       // MFMA intervals issue their DMA share after (this + 1) x 4 of their 32 MFMAs
+#endif
 // cache policy of the operand LDS-DMA (diagnostic switches; measured in DESIGN.md): nt = streaming / evict-first
 #ifdef DEVIT_DMA_A_NT
 constexpr bool DMA_A_NT = true;
@@ -156,9 +165,11 @@ __device__ __forceinline__ void dma2_perlane(const void* p0, const void* p1, uns
       : "memory", "scc");
 }
 
+// only_pair >= 0: issue just that pair of this wave's slabs (the ping-pong schedule spreads a stage's DMA instructions
+// over its barrier intervals)
 template <bool KM, int W, int NWAVES, bool NT = false>
 __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, int group, int skip,
-                                           char* lds_tile, int wave, int lane, int valid = W) {
+                                           char* lds_tile, int wave, int lane, int valid = W, int only_pair = -1) {
   constexpr int CNT = (W / 8) / NWAVES;
   static_assert(CNT % 2 == 0, "slabs are issued in pairs");
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(lds_tile) + (unsigned)(wave * CNT) * 1024u;
@@ -181,6 +192,7 @@ __device__ __forceinline__ void stage_tile(const __bf16* org, int ld, int k0, in
   const char* ubase = (const char*)org + (size_t)k0 * (KM ? (size_t)ld : (size_t)1) * 2;   // wave-uniform
 #pragma unroll
   for (int i = 0; i < CNT; i += 2)
+    if (only_pair < 0 || i == 2 * only_pair)
     dma2_uniform<NT>(ubase, lane_offset<KM, W, NWAVES>(ld, wave, lane, i, valid), lane_offset<KM, W, NWAVES>(ld, wave, lane, i + 1, valid),
                      lds0 + i * 1024u);
 }
@@ -563,6 +575,44 @@ void gemm_kernel(const GemmArgs g) {
     produce();
     wait_vmcnt<0>();
     bar();
+#if DEVIT_PP_SPREAD
+    // Spread schedule.  A K-step is four barrier intervals per group -- reads(kk=0) | MFMA(0) | reads(1) | MFMA(1) -- and
+    // the group wm = 1 runs one interval behind.  Issuing a stage's eight LDS-DMA instructions in ONE read interval
+    // (as `produce()` does) makes that interval ~850 cycles against the partner's 560 cycles of MFMAs (in-kernel stamps,
+    // tools/gemm_stamps.py).  Here the instructions are dealt over four ABSOLUTE slots q = (interval index) mod 4, the
+    // same slot for both groups at the same time (the lagging group is in its interval q - 1):
+    //   q = 0: first half of B(t+1)    q = 1: second half of B(t+1)    q = 2: first half of A(t+2)
+    //   q = 3: second half of A(t+2), then the counted wait that makes stage t+1 readable (all but A(t+2) landed)
+    // RAW: the leading group reads stage t+1 after the barrier that ends slot 3 -- every wave waited inside slot 3.
+    // WAR: B(t+1) overwrites B(t-1), last read by the lagging group in slot 3 of the previous K-step (its reads(1)),
+    //      retired by its lgkmcnt(0) in front of the barrier that ends that slot; A(t+2) overwrites A(t-1), older still.
+    auto dma_half = [&](Cursor& c, bool is_a, int h) {
+      if (is_a) {
+        stage_tile<A_KM, BM, NWAVES, DMA_A_NT>(c.ref.a, g.lda, (c.ref.kt0 + c.t) * BK, g.a_group, g.a_skip,
+                                               smem + a_slot * A_TILE_BYTES, wave, lane, BM, h);
+        if (h == 1) a_slot = a_slot + 1 == NA ? 0 : a_slot + 1;
+      } else {
+        stage_tile<B_KM, BN, NWAVES, DMA_B_NT>(c.ref.b, g.ldb, (c.ref.kt0 + c.t) * BK, g.b_group, g.b_skip,
+                                               smem + B_RING + b_slot * B_TILE_BYTES, wave, lane, min(BN, g.N - c.ref.n0), h);
+        if (h == 1) b_slot ^= 1;
+      }
+      if (h == 1) step_cursor(c);
+    };
+    auto slot_q = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if (q == 0) { if (pb.open) dma_half(pb, false, 0); }
+      if (q == 1) { if (pb.open) dma_half(pb, false, 1); }
+      if (q == 2) { a_last = pa.open; if (pa.open) dma_half(pa, true, 0); }
+      if (q == 3) { if (pa.open) dma_half(pa, true, 1); wait_stage(); }
+    };
+    // called by a wave in ITS interval p (0..3): the leading group is in absolute slot p, the lagging one in slot p + 1
+    auto spread_slot = [&](auto pc) {
+      constexpr int p = decltype(pc)::value;
+      if (wm == 0) slot_q(std::integral_constant<int, p>());
+      else slot_q(std::integral_constant<int, (p + 1) & 3>());
+    };
+    if (wm == 1) slot_q(std::integral_constant<int, 0>());   // the lagging group's slot 0 of K-step 0 lies before its first interval
+#endif
     int ca_slot = 0, cb_slot = 0;
 #ifdef DEVIT_GEMM_TSTAMP   // diagnostic build: per tile {K loop start, K loop end, epilogue end}, per K-step end of the 2nd tile
     unsigned long long* tdbg = g.ep.pos ? (unsigned long long*)g.ep.pos + ((size_t)blockIdx.x * NWAVES + wave) * 48 : nullptr;
@@ -601,7 +651,9 @@ void gemm_kernel(const GemmArgs g) {
         const char* cur_b = smem + B_RING + cb_slot * B_TILE_BYTES;
         ca_slot = ca_slot + 1 == NA ? 0 : ca_slot + 1;
         cb_slot ^= 1;
+#if !DEVIT_PP_SPREAD && !DEVIT_PP_SPLIT
         produce();                     // B of stage t+1, A of stage t+2
+#endif
         if (t == ct.nk - 1 && nw < g.N) load_cols<KIND>(ep, lane, nw, noff, bias, cs);   // under the last K-step
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -618,7 +670,30 @@ void gemm_kernel(const GemmArgs g) {
           for (int i = 0; i < MI; ++i) af[i] = read_frag<A_KM, BM, false>(cur_a, wm * WM, i, kk, lane);
 #endif
           DEVIT_STAMP(kk * 6 + 0);     // fragment reads issued
+#if DEVIT_PP_SPREAD
+          fence();
+          if (kk == 0) spread_slot(std::integral_constant<int, 0>());   // read interval of kk = 0: absolute slot 0 / 1
+          else spread_slot(std::integral_constant<int, 2>());          // read interval of kk = 1: slot 2 / 3
+          fence();
+#elif DEVIT_PP_SPLIT
+          // The stage's eight LDS-DMA instructions per wave split over the two read intervals (all eight in the first one
+          // made it ~1050 cycles against the partner's 560 cycles of MFMAs; in-kernel stamps, tools/gemm_stamps.py): B of
+          // stage t+1 behind the kk = 0 reads, A of stage t+2 behind the kk = 1 reads, then the counted wait (everything
+          // but that A request has landed -> stage t+1 readable after the next barrier).
+          fence();
+          if (kk == 0) {
+            if (pb.open) {
+              dma_b(pb);
+              step_cursor(pb);
+            }
+          } else {
+            issue_a();
+            wait_stage();
+          }
+          fence();
+#else
           if (kk == 1) wait_stage();   // stage t+1 has landed; A of stage t+2 may stay in flight
+#endif
           DEVIT_STAMP(kk * 6 + 1);     // DMA wait over
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           DEVIT_STAMP(kk * 6 + 2);     // fragments in registers
@@ -631,9 +706,18 @@ void gemm_kernel(const GemmArgs g) {
           for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
 #else
 #pragma unroll
-          for (int i = 0; i < MI; ++i)
+          for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
+#if DEVIT_PP_SPREAD
+            if (i == DEVIT_PP_MFMA_AT) {   // this interval's share of the DMA issue, behind the first MFMAs
+              fence();
+              if (kk == 0) spread_slot(std::integral_constant<int, 1>());
+              else spread_slot(std::integral_constant<int, 3>());
+              fence();
+            }
+#endif
+          }
 #endif
           DEVIT_STAMP(kk * 6 + 4);     // MFMAs issued
           bar();
