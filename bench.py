@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--teacher-lookahead", type=int, default=1,
                     help="1: teacher forward of batch k+1 runs beside the student step of batch k (default); 0: inside the step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--teacher-precision", default="f16", choices=["f16", "bf16"],
+                    help="16-bit type of the frozen teacher's forward: f16 (default; logits within 1e-3 of fp32, same MFMA rate) or bf16")
     ap.add_argument("--classes", type=int, default=0, help="override the class count (default 25 at N=1, 250 at N>1)")
     ap.add_argument("--host-input", action="store_true",
                     help="PCIe-inclusive variant (DESIGN.md section 6, never the headline value): every step's batch starts "
@@ -211,6 +213,7 @@ def main():
     teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
     for p in teacher.parameters():
         p.requires_grad_(False)
+    teacher.precision = args.teacher_precision      # frozen, forward only: IEEE f16 operands (student and all gradients: bf16)
 
     flat = ddp.FlatParams(student)
     ddp.broadcast_parameters(flat)          # before the bf16 GEMM copies are cast from the masters
@@ -382,7 +385,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
             "host_ms_per_step_idle_queue": round(host_step_ms, 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic, pinned host batches through PCIe every step" if args.host_input else "synthetic",
+            "vs_baseline": None, "dtype": "bf16", "teacher_dtype": args.teacher_precision, "data": "synthetic, pinned host batches through PCIe every step" if args.host_input else "synthetic",
             "config": {"workload": f"distill_sub step dedeit<-deit_base_distilled_patch16_224, num_division=4 "
                                    f"(C={C}), bs={B}/GPU, 224x224, hard distillation, drop_path 0.1, AdamW+EMA",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(loss_value, 5)},

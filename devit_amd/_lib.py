@@ -20,7 +20,7 @@ class Epilogue(C.Structure):
                 ("colscale", C.c_void_p), ("aux", C.c_void_p), ("aux_in", C.c_void_p), ("res", C.c_void_p),
                 ("rowscale", C.c_void_p), ("rows_per_scale", C.c_int), ("pos", C.c_void_p),
                 ("patch_tokens", C.c_int), ("extra_tokens", C.c_int), ("exact_gelu", C.c_int),
-                ("out_batch_stride", C.c_longlong), ("m_valid", C.c_int)]
+                ("out_batch_stride", C.c_longlong), ("m_valid", C.c_int), ("dtype16", C.c_int)]
 
 
 class Operand(C.Structure):
@@ -37,7 +37,7 @@ BWD_DH_PRE, BWD_DLN2, BWD_DX1, BWD_G1, BWD_DATTN, BWD_DQKV, BWD_DLN1, BWD_LNWS, 
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("n1w", "n1b", "qkv_b", "proj_b", "n2w", "n2b", "fc1_b", "fc2_b", "qkv_w16",
                                           "proj_w16", "fc1_w16", "fc2_w16", "head_gate", "neuron_gate")] + \
-               [("num_heads", C.c_int), ("attn_width", C.c_int), ("hidden", C.c_int)]
+               [("num_heads", C.c_int), ("attn_width", C.c_int), ("hidden", C.c_int), ("dtype16", C.c_int)]
 
 
 class BlockWgrads(C.Structure):
@@ -67,7 +67,7 @@ SIGNATURES = {
     "devit_last_error": (C.c_char_p, []),
     "devit_check_device": (_I, [_I]),
     "devit_gemm_bf16": (_I, [C.POINTER(Operand), C.POINTER(Operand), _I, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
-    "devit_layernorm_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "devit_layernorm_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P]),
     "devit_layernorm_bwd_workspace": (_Z, [_I, _I]),
     "devit_layernorm_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "devit_block_acts_sizes": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(C.c_size_t)]),
@@ -75,14 +75,14 @@ SIGNATURES = {
     "devit_encoder_fwd": (_I, [_I, C.POINTER(BlockWeights), C.POINTER(BlockActs), _I, _I, _I, _F, _P]),
     "devit_block_bwd": (_I, [C.POINTER(BlockWeights), C.POINTER(BlockActs), C.POINTER(BlockWgrads), C.POINTER(BlockBwdIO),
                              _I, _I, _I, _F, _P]),
-    "devit_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "devit_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "devit_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
-    "devit_im2row_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "devit_mix_im2row_bf16": (_I, [_P, _P, _I, _I, C.c_double, _I, _I, _I, _I, _P]),
+    "devit_im2row_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "devit_mix_im2row_bf16": (_I, [_P, _P, _P, _I, _I, C.c_double, _I, _I, _I, _I, _P]),
     "devit_mix_targets": (_I, [_P, _P, _I, _I, C.c_double, C.c_double, _P]),
     "devit_embed_tokens": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "devit_embed_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
-    "devit_cast_bf16": (_I, [_P, _P, _Z, _P]),
+    "devit_cast_bf16": (_I, [_P, _P, _Z, _I, _P]),
     "devit_scale_cast_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "devit_colsum_workspace": (_Z, [_I, _I]),
     "devit_colsum_bf16": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),

@@ -86,6 +86,7 @@ struct AttnFwdArgs {
 // same key order).  P never touches LDS; each lane ends up with 4 consecutive d of its own query row.
 constexpr int FWD_WAVES = 8;
 
+template <bool F16>
 __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_img = smem;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
     for (int t = 0; t < MAXT; ++t) {
       s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) s[t] = mfma16(img_row_frag(k_img, t * 16, kk, lane), qall[it][kk], s[t]);
+      for (int kk = 0; kk < 2; ++kk) s[t] = mfma16t<F16>(img_row_frag(k_img, t * 16, kk, lane), qall[it][kk], s[t]);
     }
     // raw-score row max (scale > 0); only tiles >= tmask can hold padded keys
     float mx = -INFINITY;
@@ -168,14 +169,13 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
 #pragma unroll
     for (int ks = 0; ks < 7; ++ks) {
       const f32x4 p0 = s[2 * ks], p1 = s[2 * ks + 1];
-      const bf16x8 pf = {f2bf(p0[0]), f2bf(p0[1]), f2bf(p0[2]), f2bf(p0[3]),
-                         f2bf(p1[0]), f2bf(p1[1]), f2bf(p1[2]), f2bf(p1[3])};
+      const bf16x8 pf = cvt8<F16>(p0, p1);
       const int r0 = ks * 32 + g * 4 + tq, r1 = r0 + 16;   // keys of tile 2ks / 2ks+1 for this lane group
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int ch = dt * 2 + (tp >> 1), sub = (tp & 1) * 8;
         const bf16x8 vf = cat8(lds_tr_read(v_img + img_off(r0, ch) + sub), lds_tr_read(v_img + img_off(r1, ch) + sub));
-        o[dt] = mfma16(vf, pf, o[dt]);               // O^T[d][q] += V^T[d][key] P^T[key][q]
+        o[dt] = mfma16t<F16>(vf, pf, o[dt]);         // O^T[d][q] += V^T[d][key] P^T[key][q]
       }
     }
     if (q < N) {
@@ -183,8 +183,7 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
       __bf16* orow = a.out + ((size_t)b * N + q) * D + h * HD + g * 4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x4 ov = {f2bf(o[dt][0] * sc), f2bf(o[dt][1] * sc), f2bf(o[dt][2] * sc), f2bf(o[dt][3] * sc)};
-        *(bf16x4*)(orow + dt * 16) = ov;
+        *(bf16x4*)(orow + dt * 16) = cvt4<F16>(o[dt] * sc);
       }
     }
   }
@@ -444,18 +443,23 @@ constexpr int BWD_LDS = 4 * IMG_BYTES + 2 * DST_BYTES + 2 * KROWS * 4;          
 }  // namespace
 
 extern "C" int devit_attn_fwd(const void* qkv, void* out, float* lse, const float* head_gate, int B, int N, int H,
-                              int head_dim, float scale, void* stream) {
-  DEVIT_CHECK(qkv && out, DEVIT_ERR_ARG, "devit_attn_fwd: null pointer");
+                              int head_dim, float scale, int dtype16, void* stream) {
+  DEVIT_CHECK(qkv && out && (dtype16 == 0 || dtype16 == 1), DEVIT_ERR_ARG, "devit_attn_fwd: bad argument");
   DEVIT_CHECK(head_dim == HD && N > 0 && N <= MAXT * 16 && B > 0 && H > 0, DEVIT_ERR_SHAPE,
               "devit_attn_fwd: needs head_dim == 64 and N <= 208 (got hd=%d N=%d)", head_dim, N);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
     DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "devit_attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
   AttnFwdArgs a{(const __bf16*)qkv, (__bf16*)out, lse, head_gate, B, N, H, scale};
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(FWD_WAVES * 64), FWD_LDS, (hipStream_t)stream, a);
+  if (dtype16)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(FWD_WAVES * 64), FWD_LDS, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(FWD_WAVES * 64), FWD_LDS, (hipStream_t)stream, a);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }

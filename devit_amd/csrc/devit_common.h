@@ -97,6 +97,41 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- the second 16-bit storage type: IEEE f16 ---------------------------------------------------------
+// The frozen teacher's forward can run with f16 instead of bf16 operands and stored activations (11 significand bits
+// instead of 8: logits within 1e-3 of the fp32 reference instead of 6e-3, profiles/r02_f16_emulation.json; same MFMA
+// rate; no gradients, so no loss scaling).  Fragments travel through LDS and registers as raw 16-bit lanes typed bf16x8;
+// only the MFMA opcode and the float -> 16-bit conversions differ.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16t(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// four / eight floats -> 16-bit lanes (round to nearest even in both types), returned as raw bf16-typed lanes
+template <bool F16>
+__device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
+  if constexpr (F16) {
+    const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    return __builtin_bit_cast(bf16x4, h);
+  } else {
+    return (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+  }
+}
+template <bool F16>
+__device__ __forceinline__ bf16x8 cvt8(f32x4 a, f32x4 b) {
+  if constexpr (F16) {
+    const f16x8 h = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3],
+                     (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+    return __builtin_bit_cast(bf16x8, h);
+  } else {
+    return (bf16x8){f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+  }
+}
+
 // Transposed LDS read: within each 16-lane group, lane 4q+p supplies the address of row q,
 // columns 4p..4p+3 of a 4x16 block of 16-bit elements; lane i receives column i (rows 0..3).
 __device__ __forceinline__ bf16x4 lds_tr_read(const void* lds_addr) {

@@ -6,7 +6,7 @@ namespace {
 
 // ---- im2row: image f32 [B,3,224,224] -> bf16 rows [B*196][768], k = c*256 + kh*16 + kw -------------
 // (timm PatchEmbed Conv2d(3,D,16,16) as a GEMM operand; models/de_vit.py:166-168,258)
-__global__ __launch_bounds__(256) void im2row_kernel(const float* img, __bf16* rows, int B) {
+__global__ __launch_bounds__(256) void im2row_kernel(const float* img, __bf16* rows, int B, int f16) {
   const int total = B * 196 * 96;  // 16-byte (8-element) output chunks
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int k8 = idx % 96, row = idx / 96;
@@ -14,8 +14,7 @@ __global__ __launch_bounds__(256) void im2row_kernel(const float* img, __bf16* r
     const int c = k8 >> 5, kh = (k8 >> 1) & 15, kw0 = (k8 & 1) * 8;
     const float* src = img + (((size_t)b * 3 + c) * 224 + py * 16 + kh) * 224 + px * 16 + kw0;
     const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-    bf16x8 o = {f2bf(v0[0]), f2bf(v0[1]), f2bf(v0[2]), f2bf(v0[3]), f2bf(v1[0]), f2bf(v1[1]), f2bf(v1[2]), f2bf(v1[3])};
-    *(bf16x8*)(rows + (size_t)idx * 8) = o;
+    *(bf16x8*)(rows + (size_t)idx * 8) = f16 ? cvt8<true>(v0, v1) : cvt8<false>(v0, v1);
   }
 }
 
@@ -27,7 +26,8 @@ __global__ __launch_bounds__(256) void im2row_kernel(const float* img, __bf16* r
 // and the sum are rounded separately (no FMA contraction), as the reference's tensor ops round them.
 struct MixArgs {
   const float* img;
-  __bf16* rows;
+  __bf16* rows;         // bf16 patch rows (student) or NULL
+  __bf16* rows_f16;     // the same values as IEEE f16 (f16 teacher) or NULL
   int B, mode, y0, y1, x0, x1;
   float lam, oml;      // f32(lam), f32(1 - lam) with the subtraction done in double on the host, as torch does for a python scalar
 };
@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) void mix_im2row_kernel(const MixArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (x + e >= a.x0 && x + e < a.x1) ? w[e] : v[e];
     }
-    bf16x8 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]), f2bf(v[4]), f2bf(v[5]), f2bf(v[6]), f2bf(v[7])};
-    *(bf16x8*)(a.rows + (size_t)idx * 8) = o;
+    const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+    if (a.rows) *(bf16x8*)(a.rows + (size_t)idx * 8) = cvt8<false>(lo, hi);
+    if (a.rows_f16) *(bf16x8*)(a.rows_f16 + (size_t)idx * 8) = cvt8<true>(lo, hi);
   }
 }
 
@@ -93,14 +94,17 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const float* cls, con
 }
 
 // ---- f32 -> bf16 cast (weights, once per optimizer step) ----------------------------------------------
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16* dst, size_t n) {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16* dst, size_t n, int f16) {
   const size_t n8 = n / 8;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     const f32x4 a = *(const f32x4*)(src + i * 8), b = *(const f32x4*)(src + i * 8 + 4);
-    bf16x8 o = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
-    *(bf16x8*)(dst + i * 8) = o;
+    *(bf16x8*)(dst + i * 8) = f16 ? cvt8<true>(a, b) : cvt8<false>(a, b);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = f2bf(src[n8 * 8 + threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const float v = src[n8 * 8 + threadIdx.x];
+    if (f16) ((_Float16*)dst)[n8 * 8 + threadIdx.x] = (_Float16)v;
+    else dst[n8 * 8 + threadIdx.x] = f2bf(v);
+  }
 }
 
 // ---- f32 [M][D] -> bf16 with an optional per-sample row scale (DropPath) -------------------------------
@@ -336,23 +340,24 @@ inline int grid_for(size_t work_items, int cap = 2048) {
 
 }  // namespace
 
-extern "C" int devit_im2row_bf16(const float* img, void* rows, int B, int C, int H, int W, int patch, void* stream) {
-  DEVIT_CHECK(img && rows, DEVIT_ERR_ARG, "devit_im2row_bf16: null pointer");
+extern "C" int devit_im2row_bf16(const float* img, void* rows, int B, int C, int H, int W, int patch, int dtype16,
+                                 void* stream) {
+  DEVIT_CHECK(img && rows && (dtype16 == 0 || dtype16 == 1), DEVIT_ERR_ARG, "devit_im2row_bf16: bad argument");
   DEVIT_CHECK(C == 3 && H == 224 && W == 224 && patch == 16 && B > 0, DEVIT_ERR_SHAPE,
               "devit_im2row_bf16: only 3x224x224 / patch 16 (got %dx%dx%d / %d)", C, H, W, patch);
   hipLaunchKernelGGL(im2row_kernel, dim3(grid_for((size_t)B * 196 * 96, 4096)), dim3(256), 0, (hipStream_t)stream, img,
-                     (__bf16*)rows, B);
+                     (__bf16*)rows, B, dtype16);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }
 
-extern "C" int devit_mix_im2row_bf16(const float* img, void* rows, int B, int mode, double lam, int y0, int y1, int x0, int x1,
-                                     void* stream) {
-  DEVIT_CHECK(img && rows && B > 0, DEVIT_ERR_ARG, "devit_mix_im2row_bf16: bad argument");
+extern "C" int devit_mix_im2row_bf16(const float* img, void* rows, void* rows_f16, int B, int mode, double lam, int y0,
+                                     int y1, int x0, int x1, void* stream) {
+  DEVIT_CHECK(img && (rows || rows_f16) && B > 0, DEVIT_ERR_ARG, "devit_mix_im2row_bf16: bad argument");
   DEVIT_CHECK(mode >= 0 && mode <= 2, DEVIT_ERR_ARG, "devit_mix_im2row_bf16: mode %d (0 none, 1 mixup, 2 cutmix)", mode);
   DEVIT_CHECK(mode != 2 || (0 <= y0 && y0 <= y1 && y1 <= 224 && 0 <= x0 && x0 <= x1 && x1 <= 224), DEVIT_ERR_ARG,
               "devit_mix_im2row_bf16: box [%d,%d) x [%d,%d) outside 224x224", y0, y1, x0, x1);
-  MixArgs a{img, (__bf16*)rows, B, mode, y0, y1, x0, x1, (float)lam, (float)(1.0 - lam)};
+  MixArgs a{img, (__bf16*)rows, (__bf16*)rows_f16, B, mode, y0, y1, x0, x1, (float)lam, (float)(1.0 - lam)};
   hipLaunchKernelGGL(mix_im2row_kernel, dim3(grid_for((size_t)B * 196 * 96, 4096)), dim3(256), 0, (hipStream_t)stream, a);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
@@ -378,10 +383,10 @@ extern "C" int devit_embed_tokens(const float* cls, const float* dist, const flo
   return DEVIT_OK;
 }
 
-extern "C" int devit_cast_bf16(const float* src, void* dst, size_t n, void* stream) {
-  DEVIT_CHECK(src && dst, DEVIT_ERR_ARG, "devit_cast_bf16: null pointer");
+extern "C" int devit_cast_bf16(const float* src, void* dst, size_t n, int dtype16, void* stream) {
+  DEVIT_CHECK(src && dst && (dtype16 == 0 || dtype16 == 1), DEVIT_ERR_ARG, "devit_cast_bf16: bad argument");
   DEVIT_CHECK((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, DEVIT_ERR_ARG, "devit_cast_bf16: alignment");
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n, dtype16);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }

@@ -31,12 +31,13 @@ int zero_pad(const Ctx& c, void* buf, int cols, size_t elem, int extra_rows = 0)
   return DEVIT_OK;
 }
 
-devit_epilogue make_ep(int kind, void* out, int ldc, int m_valid) {
+devit_epilogue make_ep(int kind, void* out, int ldc, int m_valid, int dtype16 = 0) {
   devit_epilogue ep = {};
   ep.kind = kind;
   ep.out = out;
   ep.ldc = ldc;
   ep.m_valid = m_valid;
+  ep.dtype16 = dtype16;
   return ep;
 }
 
@@ -75,6 +76,9 @@ int block_fwd(const Ctx& c, const devit_block_weights& w, const devit_block_acts
   TRY(check_dims(c.B, c.N, D, Da, Hd));
   DEVIT_CHECK(H > 0 && Da == H * 64, DEVIT_ERR_SHAPE, "block: attn_width %d != heads %d * 64", Da, H);
   const bool save = a.flags & DEVIT_BLK_SAVE;
+  const int t16 = w.dtype16;
+  DEVIT_CHECK(t16 == 0 || (t16 == 1 && !save), DEVIT_ERR_ARG,
+              "devit_encoder_fwd: dtype16 = %d; f16 is the frozen-teacher forward (no DEVIT_BLK_SAVE: the backward kernels are bf16)", t16);
   void* const* b = a.buf;
   DEVIT_CHECK(a.x && b[DEVIT_ACT_LN1] && b[DEVIT_ACT_QKV] && b[DEVIT_ACT_ATTN_O] && b[DEVIT_ACT_X1] && b[DEVIT_ACT_LN2] &&
                   b[DEVIT_ACT_H] && b[DEVIT_ACT_X2],
@@ -91,16 +95,16 @@ int block_fwd(const Ctx& c, const devit_block_weights& w, const devit_block_acts
   if (save) TRY(zero_pad(c, b[DEVIT_ACT_H_PRE], Hd, 2));
   // ---- x1 = x + dp1 * proj(gate * attn(qkv(ln1(x))))
   TRY(devit_layernorm_fwd(a.x, c.M, D, 0, 0, w.n1w, w.n1b, c.eps, b[DEVIT_ACT_LN1], nullptr,
-                          save ? (float*)b[DEVIT_ACT_MEAN1] : nullptr, save ? (float*)b[DEVIT_ACT_RSTD1] : nullptr, c.stream));
+                          save ? (float*)b[DEVIT_ACT_MEAN1] : nullptr, save ? (float*)b[DEVIT_ACT_RSTD1] : nullptr, t16, c.stream));
   {
-    devit_epilogue ep = make_ep(DEVIT_EPI_STORE_BF16, b[DEVIT_ACT_QKV], 3 * Da, c.M);
+    devit_epilogue ep = make_ep(DEVIT_EPI_STORE_BF16, b[DEVIT_ACT_QKV], 3 * Da, c.M, t16);
     ep.bias = w.qkv_b;
     TRY(linear_fwd(c, b[DEVIT_ACT_LN1], w.qkv_w16, 3 * Da, D, ep));
   }
   TRY(devit_attn_fwd(b[DEVIT_ACT_QKV], b[DEVIT_ACT_ATTN_O], save ? (float*)b[DEVIT_ACT_LSE] : nullptr, w.head_gate, c.B, c.N, H,
-                     64, 0.125f, c.stream));
+                     64, 0.125f, t16, c.stream));
   {
-    devit_epilogue ep = make_ep(DEVIT_EPI_RESIDUAL_F32, b[DEVIT_ACT_X1], D, c.M);
+    devit_epilogue ep = make_ep(DEVIT_EPI_RESIDUAL_F32, b[DEVIT_ACT_X1], D, c.M, t16);
     ep.bias = w.proj_b;
     ep.res = a.x;
     ep.rowscale = a.dp1;
@@ -110,16 +114,16 @@ int block_fwd(const Ctx& c, const devit_block_weights& w, const devit_block_acts
   }
   // ---- x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2(x1))))
   TRY(devit_layernorm_fwd((const float*)b[DEVIT_ACT_X1], c.M, D, 0, 0, w.n2w, w.n2b, c.eps, b[DEVIT_ACT_LN2], nullptr,
-                          save ? (float*)b[DEVIT_ACT_MEAN2] : nullptr, save ? (float*)b[DEVIT_ACT_RSTD2] : nullptr, c.stream));
+                          save ? (float*)b[DEVIT_ACT_MEAN2] : nullptr, save ? (float*)b[DEVIT_ACT_RSTD2] : nullptr, t16, c.stream));
   {
-    devit_epilogue ep = make_ep(DEVIT_EPI_GELU_BF16, b[DEVIT_ACT_H], Hd, c.M);
+    devit_epilogue ep = make_ep(DEVIT_EPI_GELU_BF16, b[DEVIT_ACT_H], Hd, c.M, t16);
     ep.bias = w.fc1_b;
     ep.colscale = w.neuron_gate;
     ep.aux = save ? b[DEVIT_ACT_H_PRE] : nullptr;
     TRY(linear_fwd(c, b[DEVIT_ACT_LN2], w.fc1_w16, Hd, D, ep));
   }
   {
-    devit_epilogue ep = make_ep(DEVIT_EPI_RESIDUAL_F32, b[DEVIT_ACT_X2], D, c.M);
+    devit_epilogue ep = make_ep(DEVIT_EPI_RESIDUAL_F32, b[DEVIT_ACT_X2], D, c.M, t16);
     ep.bias = w.fc2_b;
     ep.res = (const float*)b[DEVIT_ACT_X1];
     ep.rowscale = a.dp2;
@@ -187,6 +191,7 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
   TRY(check_dims(B, N, D, w.attn_width, Hd));
   DEVIT_CHECK(w.attn_width == D && H * 64 == D, DEVIT_ERR_SHAPE, "devit_block_bwd: compacted blocks are inference-only");
   DEVIT_CHECK(a.flags & DEVIT_BLK_SAVE, DEVIT_ERR_ARG, "devit_block_bwd: the forward ran without DEVIT_BLK_SAVE");
+  DEVIT_CHECK(w.dtype16 == 0, DEVIT_ERR_ARG, "devit_block_bwd: f16 blocks have no backward");
   DEVIT_CHECK(io->dx && io->g2 && io->dx_in, DEVIT_ERR_ARG, "devit_block_bwd: dx / g2 / dx_in");
   for (int i = 0; i < DEVIT_BWD_COUNT; ++i) DEVIT_CHECK(io->ws[i], DEVIT_ERR_ARG, "devit_block_bwd: workspace %d is null", i);
   DEVIT_CHECK(g.n1w && g.n1b && g.qkv_w && g.qkv_b && g.proj_w && g.proj_b && g.n2w && g.n2b && g.fc1_w && g.fc1_b &&

@@ -252,7 +252,9 @@ __device__ __forceinline__ void st_out(T* p, T v) {
   *p = v;
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ bf16x8 pack8(const float (&x)[8]) {
+  if constexpr (F16) return cvt8<true>((f32x4){x[0], x[1], x[2], x[3]}, (f32x4){x[4], x[5], x[6], x[7]});
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   bf16x2 p[4];
@@ -308,7 +310,7 @@ __device__ __forceinline__ void settle_cols(f32x4 (&bias)[4], f32x4 (&cs)[4]) {
   }
 }
 
-template <int KIND, int MI, bool FULL>
+template <int KIND, int MI, bool FULL, bool F16 = false>
 __device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 (&acc)[MI][4], const int (&noff)[4],
                                                 const f32x4 (&bias)[4], const f32x4 (&cs)[4], int lane, int mw,
                                                 int m_lim, size_t ob) {
@@ -365,7 +367,7 @@ __device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 
           } else {  // RESIDUAL_F32
             if (ok) {
               if (ep.aux) {
-                const bf16x4 pb = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                const bf16x4 pb = cvt4<F16>(v);
                 st_out((bf16x4*)((__bf16*)ep.aux + o + noff[j]), pb);
               }
               st_out((f32x4*)((float*)ep.out + o + noff[j]), gin[u][j] + rsc[u] * v);
@@ -380,14 +382,14 @@ __device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = acc[i][2 * q + (e >> 2)][e & 3] + bias[2 * q + (e >> 2)][e & 3];
           if (KIND == DEVIT_EPI_GELU_BF16) {
-            prec[q] = pack8(x);
+            prec[q] = pack8<F16>(x);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = gelu_fwd<false>(x[e]) * cs[2 * q + (e >> 2)][e & 3];
           } else if (KIND == DEVIT_EPI_DGELU_BF16) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = x[e] * cs[2 * q + (e >> 2)][e & 3] * gelu_bwd<false>(bf2f(pre[u][q][e]));
           }
-          outc[q] = pack8(x);
+          outc[q] = pack8<F16>(x);
         }
         // whole 128-byte rows per store: rows (c & 7) and 8 + (c & 7) of this m-tile, see swap_half_rows()
         const bool hi = c >= 8;
@@ -454,9 +456,11 @@ __device__ __forceinline__ TileRef decode_tile(const GemmArgs& g, int w) {
 // K-step (128x128) or the four-interval ping-pong schedule below (256x256).
 // Tile order: workgroups b, b+8, ... share an XCD (and its L2); each XCD owns a contiguous run of tiles (n-tile
 // fastest inside an L2-sized chunk of B, see decode_tile) and its workgroups walk that run side by side.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool A_KM, bool B_KM, int KIND>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool A_KM, bool B_KM, int KIND, bool F16 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_kernel(const GemmArgs g) {
+  static_assert(!F16 || (KIND != DEVIT_EPI_DGELU_BF16 && KIND != DEVIT_EPI_ATOMIC_F32 && !A_KM && !B_KM),
+                "f16 operands: forward layouts / epilogues only (the frozen teacher has no backward)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
@@ -708,7 +712,7 @@ void gemm_kernel(const GemmArgs g) {
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
+            for (int j = 0; j < NI; ++j) acc[i][j] = mfma16t<F16>(bfr[j], af[i], acc[i][j]);
 #if DEVIT_PP_SPREAD
             if (i == DEVIT_PP_MFMA_AT) {   // this interval's share of the DMA issue, behind the first MFMAs
               fence();
@@ -742,8 +746,8 @@ void gemm_kernel(const GemmArgs g) {
         settle_cols<KIND>(bias, cs);   // together (one after the other would double its MFMA-idle time)
         const size_t ob = (size_t)ct.bz * ep.out_batch_stride;
         const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
-        if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
-        else epilogue_direct<KIND, MI, false>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+        if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true, F16>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+        else epilogue_direct<KIND, MI, false, F16>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
       }
 #ifdef DEVIT_GEMM_TSTAMP
       if (tdbg && lane == 0 && tcount < 8) tdbg[tcount * 3 + 2] = __builtin_amdgcn_s_memtime();
@@ -811,7 +815,7 @@ void gemm_kernel(const GemmArgs g) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = DIRECT ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+            acc[i][j] = DIRECT ? mfma16t<F16>(bfr[j], af[i], acc[i][j]) : mfma16t<F16>(af[i], bfr[j], acc[i][j]);
         if constexpr (KIND == DEVIT_EPI_ATOMIC_F32) {
           if (rs_now) {
 #pragma unroll
@@ -844,8 +848,8 @@ void gemm_kernel(const GemmArgs g) {
     if constexpr (DIRECT) {
       // FULL: no row of the tile is padding -> straight-line code without per-row predicates (the predicated form makes
       // hipcc wait vmcnt(0) in front of every chunk: it cannot count stores across the skipped branches)
-      if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
-      else epilogue_direct<KIND, MI, false>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+      if (ct.m0 + BM <= m_lim) epilogue_direct<KIND, MI, true, F16>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
+      else epilogue_direct<KIND, MI, false, F16>(ep, acc, noff, bias, cs, lane, ct.m0 + wm * WM, m_lim, ob);
     } else {
       // split-K partial sums: accumulators -> this wave's private 64x64 f32 LDS tile -> one atomic per element, 64
       // consecutive floats per instruction; one pass per 64 rows of the wave tile.  The ring is empty here
@@ -938,6 +942,10 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   DEVIT_CHECK(ep->exact_gelu == 0, DEVIT_ERR_ARG, "devit_gemm_bf16: exact_gelu=1 (erff) is not built; the fused GELU uses a "
               "1.5e-7-accurate erf");
 
+  const bool f16 = ep->dtype16 != 0;
+  DEVIT_CHECK(ep->dtype16 == 0 || ep->dtype16 == 1, DEVIT_ERR_ARG, "devit_gemm_bf16: dtype16 must be 0 (bf16) or 1 (f16)");
+  DEVIT_CHECK(!f16 || (!a_kmajor && !b_kmajor && ep->kind != DEVIT_EPI_DGELU_BF16 && ep->kind != DEVIT_EPI_ATOMIC_F32),
+              DEVIT_ERR_ARG, "devit_gemm_bf16: f16 operands are built for the forward layouts / epilogues only");
   GemmArgs g;
   g.A = (const __bf16*)A; g.B = (const __bf16*)B;
   g.lda = lda; g.ldb = ldb;
@@ -1006,30 +1014,37 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   long long nwg = ((long long)cus * occ) / 8 * 8;
   if (nwg > (tiles + 7) / 8 * 8) nwg = (tiles + 7) / 8 * 8;
   hipStream_t s = (hipStream_t)stream;
-#define DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_)                                          \
+#define DEVIT_LAUNCH_ONE_T(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_, F16_)                                   \
   do {                                                                                                         \
     constexpr int ring = (3 * BM_ + 2 * BN_) * 128, stagebytes = WMM_ * WNN_ * 16384;                             \
     constexpr int lds = (KIND_ == DEVIT_EPI_ATOMIC_F32 && stagebytes > ring) ? stagebytes : ring;              \
     static bool attr = false;                                                                                  \
     if (!attr) {                                                                                               \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_>, \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_, F16_>, \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
       DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
       attr = true;                                                                                             \
     }                                                                                                          \
-    hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_>), dim3((unsigned)nwg),       \
+    hipLaunchKernelGGL((gemm_kernel<BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_, F16_>), dim3((unsigned)nwg),  \
                        dim3(WMM_* WNN_ * 64), lds, s, g);                                                      \
+  } while (0)
+#define DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_) DEVIT_LAUNCH_ONE_T(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_, false)
+  // forward layouts with f16 operands (ep->dtype16): the frozen teacher
+#define DEVIT_LAUNCH_FWD16(BM_, BN_, WMM_, WNN_, NS_, KIND_)                                                   \
+  do {                                                                                                         \
+    if (f16) DEVIT_LAUNCH_ONE_T(BM_, BN_, WMM_, WNN_, NS_, false, false, KIND_, true);                         \
+    else DEVIT_LAUNCH_ONE_T(BM_, BN_, WMM_, WNN_, NS_, false, false, KIND_, false);                            \
   } while (0)
   // the (layout, epilogue) pairs the DeViT path uses; anything else is DEVIT_ERR_ARG
 #define DEVIT_LAUNCH_GEMM(BM_, BN_, WMM_, WNN_, NS_)                                                           \
   do {                                                                                                         \
     const int key = variant * 16 + ep->kind;                                                                   \
     switch (key) {                                                                                             \
-      case 0 * 16 + DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_STORE_BF16); break;       \
-      case 0 * 16 + DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_STORE_F32); break;         \
-      case 0 * 16 + DEVIT_EPI_GELU_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_GELU_BF16); break;         \
-      case 0 * 16 + DEVIT_EPI_RESIDUAL_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_RESIDUAL_F32); break;   \
-      case 0 * 16 + DEVIT_EPI_PATCH_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, false, DEVIT_EPI_PATCH_F32); break;         \
+      case 0 * 16 + DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_FWD16(BM_, BN_, WMM_, WNN_, NS_, DEVIT_EPI_STORE_BF16); break;       \
+      case 0 * 16 + DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_FWD16(BM_, BN_, WMM_, WNN_, NS_, DEVIT_EPI_STORE_F32); break;         \
+      case 0 * 16 + DEVIT_EPI_GELU_BF16: DEVIT_LAUNCH_FWD16(BM_, BN_, WMM_, WNN_, NS_, DEVIT_EPI_GELU_BF16); break;         \
+      case 0 * 16 + DEVIT_EPI_RESIDUAL_F32: DEVIT_LAUNCH_FWD16(BM_, BN_, WMM_, WNN_, NS_, DEVIT_EPI_RESIDUAL_F32); break;   \
+      case 0 * 16 + DEVIT_EPI_PATCH_F32: DEVIT_LAUNCH_FWD16(BM_, BN_, WMM_, WNN_, NS_, DEVIT_EPI_PATCH_F32); break;         \
       case 1 * 16 + DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_STORE_BF16); break;        \
       case 1 * 16 + DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_STORE_F32); break;          \
       case 1 * 16 + DEVIT_EPI_DGELU_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_DGELU_BF16); break;        \
@@ -1042,6 +1057,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   if (cfg == 3) DEVIT_LAUNCH_GEMM(256, 256, 2, 4, 2);
   else DEVIT_LAUNCH_GEMM(128, 128, 2, 2, 2);
 #undef DEVIT_LAUNCH_ONE
+#undef DEVIT_LAUNCH_ONE_T
+#undef DEVIT_LAUNCH_FWD16
 #undef DEVIT_LAUNCH_GEMM
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;

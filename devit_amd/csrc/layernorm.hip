@@ -19,6 +19,7 @@ struct LnFwdArgs {
   float* rstd;
   int rows, D, in_group, in_stride;
   float eps;
+  int f16;              // y_bf16 holds IEEE f16 instead of bf16 (frozen-teacher forward)
 };
 
 __device__ __forceinline__ size_t ln_in_row(int r, int group, int stride) {
@@ -80,10 +81,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     for (int v = 0; v < NV; ++v) {
       const f32x4 y = (xv[v] - mu) * rs * gm[v] + bt[v];
       const size_t o = (size_t)r * a.D + (v * 32 + l32) * 4;
-      if (a.y_bf16) {
-        const bf16x4 ob = {f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
-        *(bf16x4*)(a.y_bf16 + o) = ob;
-      }
+      if (a.y_bf16) *(bf16x4*)(a.y_bf16 + o) = a.f16 ? cvt4<true>(y) : cvt4<false>(y);
       if (a.y_f32) *(f32x4*)(a.y_f32 + o) = y;
     }
   }
@@ -239,11 +237,12 @@ int dispatch_nv(int D, F&& f) {
 
 extern "C" int devit_layernorm_fwd(const float* x, int rows, int D, int in_group, int in_stride,
                                    const float* gamma, const float* beta, float eps, void* y_bf16, float* y_f32,
-                                   float* mean, float* rstd, void* stream) {
+                                   float* mean, float* rstd, int dtype16, void* stream) {
   DEVIT_CHECK(x && gamma && beta && (y_bf16 || y_f32), DEVIT_ERR_ARG, "devit_layernorm_fwd: null pointer");
+  DEVIT_CHECK(dtype16 == 0 || dtype16 == 1, DEVIT_ERR_ARG, "devit_layernorm_fwd: dtype16 must be 0 (bf16) or 1 (f16)");
   DEVIT_CHECK(rows > 0 && D % 128 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE,
               "devit_layernorm_fwd: D=%d must be a multiple of 128, <= 1024", D);
-  LnFwdArgs a{x, gamma, beta, (__bf16*)y_bf16, y_f32, mean, rstd, rows, D, in_group, in_stride, eps};
+  LnFwdArgs a{x, gamma, beta, (__bf16*)y_bf16, y_f32, mean, rstd, rows, D, in_group, in_stride, eps, dtype16};
   const int grid = rows < 8 * 2048 ? (rows + 7) / 8 : 2048;   // 8 half-waves (rows in flight) per 256-thread block
   int rc = dispatch_nv<LnFwdArgs>(D, [&](auto nv) {
     hipLaunchKernelGGL((ln_fwd_kernel<decltype(nv)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -23,15 +23,16 @@ from .registry import register_model
 __all__ = ["Mlp", "Attention", "Block", "PatchEmbed", "VisionTransformer", "model_config", "dedeit", "devit"]
 
 
-def _w16(lin):
-    """bf16 GEMM copy of an nn.Linear / Conv2d weight, refreshed when the fp32 master changed.
-    (Flat optimizers that rewrite master + bf16 through the C ABI keep both in sync themselves.)"""
+def _w16(lin, f16=False):
+    """16-bit GEMM copy of an nn.Linear / Conv2d weight (bf16; IEEE f16 for precision="f16"), refreshed when the fp32
+    master changed.  (Flat optimizers that rewrite master + bf16 through the C ABI keep both in sync themselves.)"""
     w = lin.weight
-    c = getattr(lin, "_w16", None)
+    attr = "_w16h" if f16 else "_w16"
+    c = getattr(lin, attr, None)
     if c is None or c[0] != w._version or c[1].device != w.device or c[2] != w.data_ptr():
         buf = c[1] if (c is not None and c[1].device == w.device and c[1].numel() == w.numel()) else None
-        t = ops.cast_bf16(w.detach().reshape(w.shape[0], -1), buf)
-        lin._w16 = (w._version, t, w.data_ptr())
+        t = ops.cast_bf16(w.detach().reshape(w.shape[0], -1), buf, f16=f16)
+        setattr(lin, attr, (w._version, t, w.data_ptr()))
         return t
     return c[1]
 
@@ -134,26 +135,29 @@ class Block(nn.Module):
     def drop_prob(self):
         return self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.
 
-    def block_params(self, device):
+    def block_params(self, device, f16=False):
         """Parameter view of this block for ops.EncoderFn, cached between calls: rebuilt when a weight was rewritten
         (version counter / storage), a gate was assigned, the block was (un)compacted or switched train / eval."""
         c = getattr(self, "_compact", None)
         a, m_ = self.attn, self.mlp
-        key = (device, self.training, self.drop_prob, id(c), id(a._gate), id(m_._gate),
-               id(a.qkv.__dict__.get("_w16")), id(a.proj.__dict__.get("_w16")), id(m_.fc1.__dict__.get("_w16")),
-               id(m_.fc2.__dict__.get("_w16")), a.qkv.weight._version, a.proj.weight._version, m_.fc1.weight._version, m_.fc2.weight._version,
+        wk = "_w16h" if f16 else "_w16"
+        key = (device, self.training, self.drop_prob, f16, id(c), id(a._gate), id(m_._gate),
+               id(a.qkv.__dict__.get(wk)), id(a.proj.__dict__.get(wk)), id(m_.fc1.__dict__.get(wk)),
+               id(m_.fc2.__dict__.get(wk)), a.qkv.weight._version, a.proj.weight._version, m_.fc1.weight._version, m_.fc2.weight._version,
                a.qkv.weight.data_ptr(), a.proj.weight.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc2.weight.data_ptr())
         cached = getattr(self, "_bp_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]
-        bp = self._build_block_params(device)
+        bp = self._build_block_params(device, f16)
         self._bp_cache = (key, bp)
         return bp
 
-    def _build_block_params(self, device):
+    def _build_block_params(self, device, f16=False):
         bp = ops.BlockParams()
         bp.compacted = False
         c = getattr(self, "_compact", None)
+        if f16 and c is not None:
+            raise L.DevitError('precision="f16" and shrink.compact() are not combined: uncompact the model first')
         if c is not None:            # physically shrunk weights (shrink.compact): gates folded in, masked units gone
             bp.n1w, bp.n1b, bp.n2w, bp.n2b = self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias
             bp.qkv_w = bp.proj_w = bp.fc1_w = bp.fc2_w = None
@@ -168,8 +172,8 @@ class Block(nn.Module):
         bp.n2w, bp.n2b = self.norm2.weight, self.norm2.bias
         bp.fc1_w, bp.fc1_b = self.mlp.fc1.weight, self.mlp.fc1.bias
         bp.fc2_w, bp.fc2_b = self.mlp.fc2.weight, self.mlp.fc2.bias
-        bp.qkv_w16, bp.proj_w16 = _w16(self.attn.qkv), _w16(self.attn.proj)     # (unused by the fp32 parity path)
-        bp.fc1_w16, bp.fc2_w16 = _w16(self.mlp.fc1), _w16(self.mlp.fc2)
+        bp.qkv_w16, bp.proj_w16 = _w16(self.attn.qkv, f16), _w16(self.attn.proj, f16)     # (unused by the fp32 parity path)
+        bp.fc1_w16, bp.fc2_w16 = _w16(self.mlp.fc1, f16), _w16(self.mlp.fc2, f16)
         bp.num_heads = self.attn.num_heads
         bp.head_gate, bp.neuron_gate = self.attn.gate_on(device), self.mlp.gate_on(device)
         bp.dp_prob = self.drop_prob if self.training else 0.
@@ -223,7 +227,10 @@ def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=Non
     if x.dtype != torch.float32:
         x = x.float()
     B, N, D = x.shape
-    bps = [b.block_params(x.device) for b in blocks]
+    if precision == "f16" and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in blocks for p in b.parameters())):
+        raise L.DevitError('precision="f16" is the frozen-teacher forward: no backward kernels read f16 activations; run it '
+                           'under torch.no_grad() with requires_grad off, or use precision="bf16"')
+    bps = [b.block_params(x.device, precision == "f16") for b in blocks]
     if dp_scales == "draw":
         dp_scales = draw_dp_scales(bps, B, x.device, training)
     cfg = ops.EncoderCfg(bps, training, dp_scales, want_qkv, want_att, want_enc, exact_gelu=exact_gelu,
@@ -326,7 +333,10 @@ class VisionTransformer(nn.Module):
             self.resize_encoder_mlp = nn.Linear(self.embed_dim, self.resize_dim)
         self.grad_ready = None      # set by devit_amd.ddp.BucketedGradReducer
         self.exact_gelu = 0
-        self.precision = "bf16"     # "f32": exact-fp32 parity path (ops_f32.py), not tuned
+        # "bf16": the training path.  "f16": the same kernels with IEEE f16 operands / stored activations, forward only --
+        # for frozen teachers (logits within 1e-3 of fp32 instead of 6e-3 at the same speed).  "f32": exact-fp32 parity
+        # path (ops_f32.py), not tuned
+        self.precision = "bf16"
         self.init_weights(weight_init)
 
     # ---- init / bookkeeping identical to the reference (de_vit.py:205-240) ------------------------------
@@ -368,7 +378,8 @@ class VisionTransformer(nn.Module):
             return ops_f32.PatchEmbedF32Fn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias,
                                                  self.cls_token, self.dist_token, self.pos_embed, self.grad_ready)
         return ops.PatchEmbedFn.apply(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token,
-                                      self.dist_token, self.pos_embed, _w16(self.patch_embed.proj), self.grad_ready)
+                                      self.dist_token, self.pos_embed, _w16(self.patch_embed.proj, self.precision == "f16"),
+                                      self.grad_ready)
 
     def _tokens_and_logits(self, x, with_heads):
         head = self.head if (with_heads and isinstance(self.head, nn.Linear)) else None

@@ -21,7 +21,7 @@ import torch
 from . import _lib as L
 from ._lib import call, ptr, stream_ptr
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
 ROW_TILE = 256
 
 
@@ -55,13 +55,13 @@ def workspace(device, nbytes):
 # ----------------------------------------------------------------------------------------------
 def gemm(a, lda, a_km, b, ldb, b_km, M, N, K, *, kind, out, ldc, bias=None, colscale=None, aux=None, aux_in=None,
          res=None, rowscale=None, rows_per_scale=0, pos=None, patch_tokens=0, extra_tokens=0, exact_gelu=0, batch=1,
-         a_bs=0, b_bs=0, out_bs=0, m_valid=0, split_k=1, a_group=0, a_skip=0, b_group=0, b_skip=0):
+         a_bs=0, b_bs=0, out_bs=0, m_valid=0, split_k=1, a_group=0, a_skip=0, b_group=0, b_skip=0, dtype16=0):
     if PROFILE is not None:
         return _profiled_gemm(locals())
     A = L.Operand(a.data_ptr(), lda, a_km, a_group, a_skip, a_bs)
     Bo = L.Operand(b.data_ptr(), ldb, b_km, b_group, b_skip, b_bs)
     ep = L.Epilogue(kind, out.data_ptr(), ldc, _p(bias), _p(colscale), _p(aux), _p(aux_in), _p(res), _p(rowscale),
-                    rows_per_scale, _p(pos), patch_tokens, extra_tokens, exact_gelu, out_bs, m_valid)
+                    rows_per_scale, _p(pos), patch_tokens, extra_tokens, exact_gelu, out_bs, m_valid, dtype16)
     call("devit_gemm_bf16", C.byref(A), C.byref(Bo), M, N, K, batch, split_k, C.byref(ep), stream_ptr())
 
 
@@ -143,12 +143,12 @@ def colsum(y, M, N, out, accumulate, row_group=0, row_skip=0):
 
 
 def layernorm_fwd(x2d, rows, D, gamma, beta, eps, *, y_bf16=None, y_f32=None, mean=None, rstd=None, in_group=0,
-                  in_stride=0):
+                  in_stride=0, dtype16=0):
     # algorithmic bytes: the fp32 rows in, the normalised rows out (bf16 and / or fp32)
     nbytes = rows * D * (4 + (2 if y_bf16 is not None else 0) + (4 if y_f32 is not None else 0))
     _bracketed("layernorm_fwd", nbytes, lambda: call(
         "devit_layernorm_fwd", ptr(x2d), rows, D, in_group, in_stride, ptr(gamma), ptr(beta), eps, ptr(y_bf16),
-        ptr(y_f32), ptr(mean), ptr(rstd), stream_ptr()))
+        ptr(y_f32), ptr(mean), ptr(rstd), dtype16, stream_ptr()))
 
 
 def layernorm_bwd(dy, dy_is_f32, x2d, rows, D, mean, rstd, gamma, dres, dx, dx_bf16, rowscale, rows_per_scale, dgamma,
@@ -164,11 +164,12 @@ def layernorm_bwd(dy, dy_is_f32, x2d, rows, D, mean, rstd, gamma, dres, dx, dx_b
         ptr(gsum), 1, ptr(ws), ws.numel(), stream_ptr()))
 
 
-def cast_bf16(src, dst=None):
+def cast_bf16(src, dst=None, f16=False):
+    """fp32 -> bf16 (or IEEE f16: the frozen teacher's GEMM weights) copy of a tensor."""
     src = src.contiguous()
     if dst is None:
-        dst = torch.empty(src.shape, dtype=BF16, device=src.device)
-    call("devit_cast_bf16", ptr(src), ptr(dst), src.numel(), stream_ptr())
+        dst = torch.empty(src.shape, dtype=F16 if f16 else BF16, device=src.device)
+    call("devit_cast_bf16", ptr(src), ptr(dst), src.numel(), int(dst.dtype == F16), stream_ptr())
     return dst
 
 
@@ -216,37 +217,41 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
     M, H, dev = B * N, bp.num_heads, x.device
     x2 = x.view(M, D)
     s = {}
+    t16 = 1 if bp.qkv_w16.dtype == F16 else 0       # f16: the frozen teacher's forward (no backward)
+    BF16 = F16 if t16 else torch.bfloat16
+    if t16 and need_grad:
+        raise L.DevitError('precision="f16" is forward-only (frozen teacher): run it under torch.no_grad()')
     ln1 = rows_alloc(M, D, BF16, dev)
     mean1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     rstd1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
-    layernorm_fwd(x2, M, D, bp.n1w, bp.n1b, cfg.eps, y_bf16=ln1, mean=mean1, rstd=rstd1)
+    layernorm_fwd(x2, M, D, bp.n1w, bp.n1b, cfg.eps, y_bf16=ln1, mean=mean1, rstd=rstd1, dtype16=t16)
     Da = bp.qkv_w16.shape[0] // 3          # attention width = heads * 64 (== D unless the block was compacted, shrink.py)
     # the attention kernels never read rows >= B*N; the relation-loss windows (RelationLossFn) overhang by up to 128
     qkv = rows_alloc(M, 3 * Da, BF16, dev, extra=128 if pad_qkv else 0)
-    linear_fwd(ln1, bp.qkv_w16, bp.qkv_b, M, out=qkv)
+    linear_fwd(ln1, bp.qkv_w16, bp.qkv_b, M, out=qkv, dtype16=t16)
     attn_o = rows_alloc(M, Da, BF16, dev)
     lse = torch.empty((B, H, N), dtype=F32, device=dev) if need_grad else None
     # algorithmic bytes: q, k, v in, the head outputs out (bf16)
     _bracketed("attention_fwd", M * Da * 2 * 4, lambda: call(
         "devit_attn_fwd", ptr(qkv), ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, N, H, Da // H, (Da // H) ** -0.5,
-        stream_ptr()))
+        t16, stream_ptr()))
     x1 = torch.empty((B, N, D), dtype=F32, device=dev)
     att = torch.empty((M, D), dtype=BF16, device=dev) if want_att else None
     dp1, dp2 = dp if dp is not None else (None, None)
     linear_fwd(attn_o, bp.proj_w16, bp.proj_b, M, out=x1.view(M, D), kind=L.EPI_RESIDUAL_F32, res=x2, rowscale=dp1,
-               rows_per_scale=N, aux=att)
+               rows_per_scale=N, aux=att, dtype16=t16)
     ln2 = rows_alloc(M, D, BF16, dev)
     mean2 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     rstd2 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
-    layernorm_fwd(x1.view(M, D), M, D, bp.n2w, bp.n2b, cfg.eps, y_bf16=ln2, mean=mean2, rstd=rstd2)
+    layernorm_fwd(x1.view(M, D), M, D, bp.n2w, bp.n2b, cfg.eps, y_bf16=ln2, mean=mean2, rstd=rstd2, dtype16=t16)
     Hd = bp.fc1_w16.shape[0]
     h = rows_alloc(M, Hd, BF16, dev)
     h_pre = rows_alloc(M, Hd, BF16, dev) if need_grad else None
     linear_fwd(ln2, bp.fc1_w16, bp.fc1_b, M, out=h, kind=L.EPI_GELU_BF16, colscale=bp.neuron_gate, aux=h_pre,
-               exact_gelu=cfg.exact_gelu)
+               exact_gelu=cfg.exact_gelu, dtype16=t16)
     x2o = torch.empty((B, N, D), dtype=F32, device=dev)
     linear_fwd(h, bp.fc2_w16, bp.fc2_b, M, out=x2o.view(M, D), kind=L.EPI_RESIDUAL_F32, res=x1.view(M, D), rowscale=dp2,
-               rows_per_scale=N)
+               rows_per_scale=N, dtype16=t16)
     if bp.module is not None:  # shrink contract (core/imp_rank.py:31,108): post-mask values
         bp.module.mlp.neuron_output = h[:M].view(B, N, Hd)
         bp.module.attn.head_output = attn_o[:M].view(B, N, H, Da // H)
@@ -376,6 +381,7 @@ def _weights_struct(bp):
     w.fc1_w16, w.fc2_w16 = bp.fc1_w16.data_ptr(), bp.fc2_w16.data_ptr()
     w.head_gate, w.neuron_gate = _p(bp.head_gate), _p(bp.neuron_gate)
     w.num_heads, w.attn_width, w.hidden = bp.num_heads, bp.qkv_w16.shape[0] // 3, bp.fc1_w16.shape[0]
+    w.dtype16 = 1 if bp.qkv_w16.dtype == F16 else 0
     return w
 
 
@@ -401,6 +407,9 @@ def _encoder_forward_composite(x, cfg, need_grad):
         pad = bool(cfg.want_qkv) and (cfg.qkv_pad_layers is None or i in cfg.qkv_pad_layers)
         flags = (L.BLK_SAVE if need_grad else 0) | (L.BLK_QKV_PAD if pad else 0) | (L.BLK_ATT if cfg.want_att else 0)
         Da, Hd = weights[i].attn_width, weights[i].hidden
+        BF16 = F16 if weights[i].dtype16 else torch.bfloat16
+        if weights[i].dtype16 and need_grad:
+            raise L.DevitError('precision="f16" is forward-only (frozen teacher): run it under torch.no_grad()')
         sz, offs, tot = _act_sizes(B, N, D, Da, Hd, flags)
         arena = _arena(tot, dev)
         run.arena.append(arena)
@@ -583,40 +592,57 @@ class PatchRows:
     (`patch_rows`) or fused with Mixup / CutMix (`mix_patch_rows`) -- serves the student, the teacher and all MultiViT
     backbones of a step.  Quacks like the image batch where host code only asks for its size and place."""
 
-    def __init__(self, rows, B):
-        self.rows, self.B = rows, B
+    def __init__(self, rows, B, rows_f16=None):
+        self.rows, self.rows_f16, self.B = rows, rows_f16, B          # bf16 rows and / or the same values in IEEE f16
         self.shape = (B, 3, 224, 224)
 
-    is_cuda = property(lambda self: self.rows.is_cuda)
-    device = property(lambda self: self.rows.device)
+    _any = property(lambda self: self.rows if self.rows is not None else self.rows_f16)
+    is_cuda = property(lambda self: self._any.is_cuda)
+    device = property(lambda self: self._any.device)
     dtype = torch.float32
 
+    def of(self, dtype):
+        t = self.rows_f16 if dtype == F16 else self.rows
+        if t is None:
+            raise L.DevitError(f"PatchRows holds no {dtype} rows: build them with patch_rows(img, dtypes=...) / "
+                               "mix_patch_rows(..., dtypes=...) for every precision the models of the step run in")
+        return t
+
     def record_stream(self, s):
-        self.rows.record_stream(s)
+        for t in (self.rows, self.rows_f16):
+            if t is not None:
+                t.record_stream(s)
 
 
-def patch_rows(img):
-    """fp32 [B,3,224,224] -> PatchRows (devit_im2row_bf16)."""
+PATCH_ROW_DTYPES = (torch.bfloat16,)      # what patch_rows / mix_patch_rows produce by default
+
+
+def patch_rows(img, dtypes=None):
+    """fp32 [B,3,224,224] -> PatchRows (devit_im2row_bf16); dtypes: which 16-bit copies to make (bf16 and / or f16)."""
     if isinstance(img, PatchRows):
         return img
     L.require_device(img)
     img = img.contiguous().float()
     B = img.shape[0]
-    rows = rows_alloc(B * 196, 768, BF16, img.device)
-    call("devit_im2row_bf16", ptr(img), ptr(rows), B, 3, 224, 224, 16, stream_ptr())
-    return PatchRows(rows, B)
+    out = {}
+    for dt in (dtypes or PATCH_ROW_DTYPES):
+        out[dt] = rows_alloc(B * 196, 768, dt, img.device)
+        call("devit_im2row_bf16", ptr(img), ptr(out[dt]), B, 3, 224, 224, 16, int(dt == F16), stream_ptr())
+    return PatchRows(out.get(torch.bfloat16), B, out.get(F16))
 
 
-def mix_patch_rows(img, mode, lam=1.0, box=(0, 0, 0, 0)):
+def mix_patch_rows(img, mode, lam=1.0, box=(0, 0, 0, 0), dtypes=None):
     """Mixup (mode 1) / CutMix (mode 2, box = (y0, y1, x0, x1)) of a batch with its flip, straight to patch rows
     (devit_mix_im2row_bf16; timm Mixup mode='batch', engine.py:65-66)."""
     L.require_device(img)
     img = img.contiguous().float()
     B = img.shape[0]
-    rows = rows_alloc(B * 196, 768, BF16, img.device)
-    call("devit_mix_im2row_bf16", ptr(img), ptr(rows), B, int(mode), float(lam), int(box[0]), int(box[1]), int(box[2]),
-         int(box[3]), stream_ptr())
-    return PatchRows(rows, B)
+    dtypes = dtypes or PATCH_ROW_DTYPES
+    rows = rows_alloc(B * 196, 768, torch.bfloat16, img.device) if torch.bfloat16 in dtypes else None
+    rows_h = rows_alloc(B * 196, 768, F16, img.device) if F16 in dtypes else None
+    call("devit_mix_im2row_bf16", ptr(img), ptr(rows), ptr(rows_h), B, int(mode), float(lam), int(box[0]), int(box[1]),
+         int(box[2]), int(box[3]), stream_ptr())
+    return PatchRows(rows, B, rows_h)
 
 
 def mix_targets(labels, num_classes, lam, smoothing):
@@ -631,15 +657,16 @@ def mix_targets(labels, num_classes, lam, smoothing):
 class PatchEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, proj_w, proj_b, cls_token, dist_token, pos_embed, w16, grad_ready):
-        pre = img if isinstance(img, PatchRows) else patch_rows(img)
-        rows, B, dev = pre.rows, pre.B, pre.rows.device
+        pre = img if isinstance(img, PatchRows) else patch_rows(img, (w16.dtype,))
+        rows, B = pre.of(w16.dtype), pre.B
+        dev = rows.device
         D = proj_w.shape[0]
         ntok = 2 if dist_token is not None else 1
         T = 196 + ntok
         M = B * 196
         x = torch.empty((B, T, D), dtype=F32, device=dev)
         gemm(rows, 768, 0, w16, 768, 0, pad_rows(M), D, 768, kind=L.EPI_PATCH_F32, out=x, ldc=D, bias=proj_b,
-             pos=pos_embed, patch_tokens=196, extra_tokens=ntok, m_valid=M)
+             pos=pos_embed, patch_tokens=196, extra_tokens=ntok, m_valid=M, dtype16=int(w16.dtype == F16))
         call("devit_embed_tokens", ptr(cls_token), ptr(dist_token), ptr(pos_embed), ptr(x), B, T, D, stream_ptr())
         ctx.rows, ctx.dims = rows, (B, T, D, ntok)
         ctx.params = (proj_w, proj_b, cls_token, dist_token, pos_embed)
@@ -859,7 +886,7 @@ class RelationLossFn(torch.autograd.Function):
             for buf, Dm, out in ((t_qkv, Dt, gt), (s_qkv, Ds, gs)):
                 f = buf[:, j * Dm:]
                 gemm(f, 3 * Dm, 0, f, 3 * Dm, 0, 256, 256, Dm, kind=L.EPI_STORE_F32, out=out, ldc=256, batch=B,
-                     a_bs=N * 3 * Dm, b_bs=N * 3 * Dm, out_bs=256 * 256)
+                     a_bs=N * 3 * Dm, b_bs=N * 3 * Dm, out_bs=256 * 256, dtype16=int(buf.dtype == F16))
             lse_t = torch.empty((B, N), dtype=F32, device=dev)
             lse_s = torch.empty((B, N), dtype=F32, device=dev)
             row_kl = torch.empty((B, N), dtype=F32, device=dev)

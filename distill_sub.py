@@ -67,6 +67,8 @@ def get_args_parser():
     a('--load_shrink', action='store_true', default=False); a('--shrink_checkpoint', type=str, default='')
     a('--neuron_shrinking', action='store_true', default=False); a('--head_shrinking', action='store_true', default=False)
     a('--synthetic', type=int, default=0, metavar='STEPS', help='train on STEPS random on-device batches per epoch')
+    a('--teacher-precision', default='f16', choices=['f16', 'bf16'],
+      help="16-bit type of the frozen teacher's forward (f16: logits within 1e-3 of fp32 at the bf16 speed)")
     a('--no-teacher-lookahead', dest='teacher_lookahead', action='store_false',
       help='run the frozen teacher inside the step instead of one batch ahead (engine.TeacherLookahead)')
     return p
@@ -234,6 +236,10 @@ def main(args):
         teacher.to(device).eval()
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
+        teacher.precision = args.teacher_precision
+        if args.teacher_precision == 'f16':         # Mixup's fused im2row then emits the patch rows in both 16-bit types
+            from devit_amd import ops
+            ops.PATCH_ROW_DTYPES = (torch.bfloat16, torch.float16)
 
     flat = ddp.FlatParams(model)
     ddp.broadcast_parameters(flat)          # ranks are seeded seed + rank: rank 0's weights first, then the bf16 copies

@@ -90,6 +90,8 @@ typedef struct {
   int exact_gelu;          /* must be 0: the fused GELU is a fitted form, |err| <= 2.6e-5 (erff() variant not built) */
   long long out_batch_stride; /* elements between consecutive batch outputs (out, aux, aux_in, res) */
   int m_valid;             /* > 0: rows m >= m_valid of each batch are not stored */
+  int dtype16;             /* 16-bit type of A, B and of any 16-bit output of the launch: 0 = bf16, 1 = IEEE f16 (forward
+                              layouts and epilogues only: the frozen teacher's forward, 11 significand bits instead of 8) */
 } devit_epilogue;
 
 typedef struct {
@@ -118,7 +120,7 @@ int devit_gemm_bf16(const devit_operand* A, const devit_operand* B, int M, int N
  * ---------------------------------------------------------------------------------------- */
 int devit_layernorm_fwd(const float* x, int rows, int D, int in_group, int in_stride, const float* gamma,
                         const float* beta, float eps, void* y_bf16, float* y_f32, float* mean, float* rstd,
-                        void* stream);
+                        int dtype16 /* type of y_bf16: 0 bf16, 1 f16 */, void* stream);
 size_t devit_layernorm_bwd_workspace(int rows, int D);
 int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows, int D, int in_group, int in_stride,
                         const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
@@ -135,7 +137,7 @@ int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows,
  * bwd: dqkv (same layout as qkv) from dout; dqkv_add (optional, same layout) is added in.
  * ---------------------------------------------------------------------------------------- */
 int devit_attn_fwd(const void* qkv, void* out, float* lse, const float* head_gate, int B, int N, int H, int head_dim,
-                   float scale, void* stream);
+                   float scale, int dtype16 /* type of qkv and out: 0 bf16, 1 f16 */, void* stream);
 int devit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* head_gate,
                    const void* dqkv_add, void* dqkv, int B, int N, int H, int head_dim, float scale, void* stream);
 
@@ -170,6 +172,8 @@ typedef struct {
   const void *qkv_w16, *proj_w16, *fc1_w16, *fc2_w16;   /* bf16 [out][in] */
   const float *head_gate, *neuron_gate;                 /* [heads] / [hidden] or NULL (= 1) */
   int num_heads, attn_width, hidden;                    /* attn_width = heads * 64 (== D unless compacted) */
+  int dtype16;                                          /* 16-bit type of the weights and of every stored activation: 0 bf16,
+                                                           1 f16 (forward without DEVIT_BLK_SAVE only) */
 } devit_block_weights;
 
 typedef struct {
@@ -219,14 +223,14 @@ int devit_block_bwd(const devit_block_weights* w, const devit_block_acts* acts, 
  * embed_bwd: dpos[T][D] = sum_b dx[b]; dcls = dpos[0]; ddist = dpos[1]; dbias = sum_{t>=ntok} dpos[t];
  *   dx_bf16 (optional) = bf16 copy of dx for the patch-projection wgrad.
  * ---------------------------------------------------------------------------------------- */
-int devit_im2row_bf16(const float* img, void* rows, int B, int C, int H, int W, int patch, void* stream);
+int devit_im2row_bf16(const float* img, void* rows, int B, int C, int H, int W, int patch, int dtype16, void* stream);
 /* On-device input stage (engine.py:65-66: timm Mixup(mode='batch') on the fp32 batch, then patch_embed): the mixed batch is
  * produced directly as the bf16 patch rows both models' patch-embedding GEMMs read -- one pass over the images.
  *   mode 0: plain im2row; 1: mixup  lam * x + (1 - lam) * x.flip(0);  2: cutmix  x[:, :, y0:y1, x0:x1] = x.flip(0)[...]
  *   (lam, the box and the mixup / cutmix draw are host-side numpy RNG in timm; they are arguments here).
  * devit_mix_targets: [B][C] f32 = lam * smooth_one_hot(y) + (1 - lam) * smooth_one_hot(y.flip(0)), int64 labels. */
-int devit_mix_im2row_bf16(const float* img, void* rows, int B, int mode, double lam, int y0, int y1, int x0, int x1,
-                          void* stream);
+int devit_mix_im2row_bf16(const float* img, void* rows /* bf16 or NULL */, void* rows_f16 /* f16 or NULL */, int B, int mode,
+                          double lam, int y0, int y1, int x0, int x1, void* stream);
 int devit_mix_targets(const long long* labels, float* targets, int B, int C, double lam, double smoothing, void* stream);
 int devit_embed_tokens(const float* cls, const float* dist, const float* pos, float* x, int B, int T, int D,
                        void* stream);
@@ -234,7 +238,7 @@ int devit_embed_bwd(const float* dx, int B, int T, int D, int ntok, float* dpos,
                     float* dbias, void* dx_bf16, int accumulate, void* stream);
 
 /* f32 -> bf16 cast of a flat buffer (weights, once per optimizer step). */
-int devit_cast_bf16(const float* src, void* dst, size_t n, void* stream);
+int devit_cast_bf16(const float* src, void* dst, size_t n, int dtype16, void* stream);
 
 /* dst_bf16[m][d] = bf16(src[m][d] * (rowscale ? rowscale[m / rows_per_scale] : 1)): turns the fp32
  * residual-stream gradient into the bf16 branch gradient (DropPath scale folded, de_vit.py:114-115). */

@@ -84,11 +84,11 @@ def test_attention_rows_sum_to_gate_full_size(dev):
     gate = torch.tensor([1.0, 0.0, 0.5, 1.0, 2.0, 1.0], device=dev)
     out = ops.rows_alloc(M, D, BF16, dev)
     lse = torch.empty((B, H, N), dtype=F32, device=dev)
-    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, stream_ptr())
+    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, 0, stream_ptr())
     o = out[:M].float().view(M, H, 64)
     assert float((o - gate.view(1, H, 1)).abs().max()) < 2 ** -7 * 2.0
     qkv[:M, : 2 * D] = 0.0                                            # all scores 0 -> lse = log N exactly-ish
-    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, stream_ptr())
+    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, 0, stream_ptr())
     assert float((lse - torch.log(torch.tensor(float(N)))).abs().max()) < 1e-5
 
 
@@ -144,7 +144,7 @@ def test_attention_backward_full_size(dev, H, with_add):
     gate[1], gate[2] = 0.0, 0.5
     out = ops.rows_alloc(M, D, BF16, dev)
     lse = torch.empty((B, H, N), dtype=F32, device=dev)
-    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, stream_ptr())
+    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, 0, stream_ptr())
     dout = ops.rows_alloc(M, D, BF16, dev)
     dout[:M] = torch.randn((M, D), generator=g, device=dev).to(BF16)
     add = None

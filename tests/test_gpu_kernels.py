@@ -291,7 +291,7 @@ def test_attention_fwd_bwd(dev, B, N, H):
         gate[1] = 0.0
     out = ops.rows_alloc(M, D, BF16, dev)
     lse = torch.empty((B, H, N), dtype=F32, device=dev)
-    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, stream_ptr())
+    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(gate), B, N, H, 64, 0.125, 0, stream_ptr())
     q32 = qkv[:M].float().requires_grad_(True)
     ref, _ = attn_ref(q32, B, N, H, gate)
     bf16_ulp_ok(out[:M], ref, extra=2e-3)      # P is rounded to bf16 before P V
@@ -325,7 +325,7 @@ def test_im2row_embed_cast_colsum(dev):
     B = 3
     img = rnd((B, 3, 224, 224), dev)
     rows = ops.rows_alloc(B * 196, 768, BF16, dev)
-    call("devit_im2row_bf16", ptr(img), ptr(rows), B, 3, 224, 224, 16, stream_ptr())
+    call("devit_im2row_bf16", ptr(img), ptr(rows), B, 3, 224, 224, 16, 0, stream_ptr())
     ref = img.reshape(B, 3, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(B * 196, 768).to(BF16)
     assert torch.equal(rows[: B * 196], ref)
     y = rnd((1000, 384), dev, dtype=BF16)

@@ -8,6 +8,6 @@ out = ops.rows_alloc(M, D, torch.bfloat16, dev); lse = torch.empty(B, H, N, devi
 dout = ops.rows_alloc(M, D, torch.bfloat16, dev); dout[:M] = torch.randn(M, D, device=dev).to(torch.bfloat16)
 dqkv = ops.rows_alloc(M, 3 * D, torch.bfloat16, dev)
 for _ in range(3):
-    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), None, B, N, H, 64, 0.125, stream_ptr())
+    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), None, B, N, H, 64, 0.125, 0, stream_ptr())
     call("devit_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), None, None, ptr(dqkv), B, N, H, 64, 0.125, stream_ptr())
 torch.cuda.synchronize()

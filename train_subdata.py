@@ -69,6 +69,10 @@ def main(args):
         teacher.to(device).eval()
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
+        teacher.precision = args.teacher_precision
+        if args.teacher_precision == 'f16':
+            from devit_amd import ops
+            ops.PATCH_ROW_DTYPES = (torch.bfloat16, torch.float16)
 
     flat = ddp.FlatParams(model)
     ddp.broadcast_parameters(flat)          # ranks are seeded seed + rank: rank 0's weights first, then the bf16 copies
