@@ -815,7 +815,7 @@ class AttentionFn(torch.autograd.Function):
         linear_fwd(xb, wq16, bq, M, out=qkv)
         o = rows_alloc(M, D, BF16, dev)
         lse = torch.empty((B, H, N), dtype=F32, device=dev) if need else None
-        call("devit_attn_fwd", ptr(qkv), ptr(o), ptr(lse), ptr(gate), B, N, H, D // H, (D // H) ** -0.5, stream_ptr())
+        call("devit_attn_fwd", ptr(qkv), ptr(o), ptr(lse), ptr(gate), B, N, H, D // H, (D // H) ** -0.5, 0, stream_ptr())
         y = torch.empty((B, N, D), dtype=F32, device=dev)
         linear_fwd(o, wp16, bp_, M, out=y.view(M, D), kind=L.EPI_STORE_F32)
         module.head_output = o[:M].view(B, N, H, D // H)

@@ -91,3 +91,33 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
+
+
+def test_call_sites_match_signatures():
+    """Every `call("devit_...", ...)` in the package passes exactly as many arguments as `_lib.SIGNATURES` declares for that
+    entry point.  ctypes only checks this when the call executes, i.e. on the GPU box: a stale call site left behind by a
+    C-ABI change (round 2: `dtype16` added to devit_attn_fwd) otherwise surfaces there and nowhere else."""
+    import ast
+    from devit_amd import _lib
+    pkg = os.path.join(ROOT, "devit_amd")
+    seen, bad = 0, []
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read(), fn)
+        for node in ast.walk(tree):
+            if not (isinstance(node, ast.Call) and getattr(node.func, "id", getattr(node.func, "attr", None)) == "call"):
+                continue
+            if not node.args or not isinstance(node.args[0], ast.Constant) or not str(node.args[0].value).startswith("devit_"):
+                continue
+            name = node.args[0].value
+            if any(isinstance(a, ast.Starred) for a in node.args) or node.keywords:
+                continue                      # argument list built at run time: not checkable statically
+            seen += 1
+            if name not in _lib.SIGNATURES:
+                bad.append(f"{fn}:{node.lineno}: {name} is not in _lib.SIGNATURES")
+            elif len(node.args) - 1 != len(_lib.SIGNATURES[name][1]):
+                bad.append(f"{fn}:{node.lineno}: {name} called with {len(node.args) - 1} arguments, "
+                           f"declared with {len(_lib.SIGNATURES[name][1])}")
+    assert seen > 40, f"only {seen} call sites found: the scan is not seeing the package"
+    assert not bad, "\n".join(bad)

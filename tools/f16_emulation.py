@@ -21,7 +21,8 @@ from oracle.detgen import det_array
 torch.set_num_threads(8)
 
 
-def forward(st, geom, img, q):
+def forward(st, geom, img, q, trace=None):
+    """trace: optional list that receives the fp32 residual stream after the embedding and after every block."""
     H, depth = geom["num_heads"], geom["depth"]
     w = lambda k: q(st[k])
     B = img.shape[0]
@@ -30,6 +31,8 @@ def forward(st, geom, img, q):
     x = rows @ w("patch_embed.proj.weight").reshape(D, 768).t() + st["patch_embed.proj.bias"]
     x = torch.cat([st["cls_token"].expand(B, -1, -1), st["dist_token"].expand(B, -1, -1), x], 1) + st["pos_embed"]
     hd, qkv_mid = D // H, None
+    if trace is not None:
+        trace.append(x.clone())
     for i in range(depth):
         p = f"blocks.{i}."
         ln1 = q(F.layer_norm(x, (D,), st[p + "norm1.weight"], st[p + "norm1.bias"], O.LN_EPS))
@@ -46,6 +49,8 @@ def forward(st, geom, img, q):
         x = x + F.linear(h, w(p + "mlp.fc2.weight"), st[p + "mlp.fc2.bias"])
         if i == depth // 2 - 1:
             qkv_mid = v
+        if trace is not None:
+            trace.append(x.clone())
     x = F.layer_norm(x, (D,), st["norm.weight"], st["norm.bias"], O.LN_EPS)
     lo = F.linear(x[:, 0], st["head.weight"], st["head.bias"])
     lk = F.linear(x[:, 1], st["head_dist.weight"], st["head_dist.bias"])
