@@ -491,11 +491,13 @@ def test_distillation_loss_vs_golden(golden, dev):
 
 # ------------------------------------------------------------------------------------------ f16 frozen-teacher forward
 # Measured on MI355X (round 2, first GPU run of this path): f16 teacher logits deviate 1.126e-3 of max|logit| from the
-# reference -- 6x closer than bf16 (6.8e-3) but NOT inside BASELINE.json's 1e-3.  The CPU emulation of the storage points
-# predicted 7.0e-4 (7.8e-4 with the kernels' fitted GELU in place of erf, tools/f16_emulation.py); the remaining gap is
-# not explained yet (tools/f16_localise.py compares the stored intermediates layer by layer).  The 1e-3 claim therefore
-# lives in a strict xfail below: it shows in every run, and turns red the day a fix brings the path under the bar so that
-# the marker has to go.  Only precision="f32" (test_f32_path_meets_1e3_bar) meets 1e-3 today.
+# reference on the 8-image golden -- 6x closer than bf16 (6.8e-3) but NOT inside BASELINE.json's 1e-3.  This is not a kernel
+# defect: per block, the GPU residual stream tracks the CPU emulation of f16 storage (profiles/r02_b_f16_localise.txt: after
+# block 11, 5.6e-4 from the fp32 reference on the GPU vs 6.4e-4 emulated), and the logit statistic (a max over rounding noise)
+# moves by +-40 % between samples: emulation 7.0e-4 on 8 images but 1.02e-3 on 2, GPU 1.13e-3 on 8 but 8.2e-4 on 2.  f16
+# storage lands AROUND 1e-3, straddling the bar; the earlier "7.0e-4 predicted" was one draw read as margin.  The 1e-3 claim
+# therefore lives in a strict xfail below: it shows in every run, and turns red if the path ever gets under the bar so that
+# the marker has to go.  Only precision="f32" (test_f32_path_meets_1e3_bar) meets 1e-3.
 F16_LOGITS_MEASURED = 1.126e-3
 F16_LOGITS_REGRESSION_BAR = 2.3e-3        # ~2x measured, as for the bf16 bars above
 
@@ -514,8 +516,9 @@ def _f16_teacher_logits(models, dev):
         t.precision = "bf16"
 
 
-@pytest.mark.xfail(strict=True, reason="f16 teacher forward measured 1.126e-3 on MI355X: misses BASELINE.json's 1e-3 "
-                                       "(emulation predicted 7.0e-4; gap unexplained, see tools/f16_localise.py)")
+@pytest.mark.xfail(strict=True, reason="f16 teacher forward measured 1.126e-3 on MI355X: misses BASELINE.json's 1e-3; "
+                                       "f16 storage lands around 1e-3 (kernels track the emulation per block, "
+                                       "profiles/r02_b_f16_localise.txt)")
 def test_f16_teacher_forward_meets_1e3_bar(golden, models, dev):
     """BASELINE.json's bar, unchanged, on the benchmarked kernels with f16 operands.  Expected to fail until the path is fixed."""
     e = rel(_f16_teacher_logits(models, dev), golden("model_deitb")["logits"])

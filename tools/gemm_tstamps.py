@@ -9,9 +9,13 @@ M = 50688; N = int(sys.argv[1]) if len(sys.argv) > 1 else 2304; K = int(sys.argv
 kind = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device("cuda")
 a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
-out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+# the stamp build borrows ep.pos as its debug buffer: only kinds that never read pos (not PATCH), forward layouts only
+assert kind in (L.EPI_STORE_BF16, L.EPI_GELU_BF16, L.EPI_RESIDUAL_F32, L.EPI_STORE_F32), f"kind {kind} is not supported by this tool"
+f32_out = kind in (L.EPI_RESIDUAL_F32, L.EPI_STORE_F32)           # the epilogue writes M x N floats: size the buffer for them
+out = torch.empty(M, N, dtype=torch.float32 if f32_out else torch.bfloat16, device=dev)
+res = torch.randn(M, N, device=dev) if kind == L.EPI_RESIDUAL_F32 else None
 dbg = torch.zeros(256 * 8 * 48, dtype=torch.int64, device=dev)
-fn = lambda: ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, pos=dbg.view(torch.float32), bias=torch.zeros(N, device=dev))
+fn = lambda: ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, pos=dbg.view(torch.float32), bias=torch.zeros(N, device=dev), res=res)
 for _ in range(5): fn()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
