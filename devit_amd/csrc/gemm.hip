@@ -9,7 +9,6 @@
 // Epilogues run straight from the accumulators (epilogue_direct): the MFMAs take the weight operand on their row
 // side so each lane owns consecutive output columns; only the split-K atomic epilogue stages through LDS.
 #include <stdlib.h>
-#include <string.h>
 
 #include <type_traits>
 
@@ -71,11 +70,6 @@ struct GemmArgs {
   int tiles_m, tiles_n, split_k, total_tiles;
   FastDiv d_per_z, d_chunk, d_gn, d_last, d_split;   // tiles per z-slice, per n-chunk; chunk widths; split_k
   int gn;  // n-tiles per L2 chunk: tiles are ordered chunk-major, then m, then n inside the chunk
-  // De-phasing (diagnostic, DEVIT_GEMM_STAGGER): persistent workgroups start together and have equal tile times, so all of
-  // them reach their epilogues at once (an HBM burst while every MFMA pipe idles).  stagger_cycles > 0 delays a workgroup's
-  // start by stagger_cycles * phase / 8; mode 1: only workgroups with fewer tiles than the busiest one (free slack),
-  // mode 2: every workgroup.
-  int stagger_cycles, stagger_mode;
   devit_epilogue ep;
 };
 
@@ -503,15 +497,6 @@ void gemm_kernel(const GemmArgs g) {
     last = start + q + (xcd < r ? 1 : 0);
   }
   if (first >= last) return;
-  if (g.stagger_cycles > 0) {
-    // tiles of this workgroup vs of the busiest one in its XCD (idx = 0); all wave-uniform, the loop is bounded by time
-    const int mine = (last - first + stride - 1) / stride, most = (last - (first - idx) + stride - 1) / stride;
-    if (g.stagger_mode == 2 || mine < most) {
-      const unsigned phase = (unsigned)(idx * 5) & 7u;            // 0..7, neighbouring workgroups far apart
-      const unsigned long long wait = (unsigned long long)g.stagger_cycles * phase / 8, t0 = __builtin_amdgcn_s_memtime();
-      while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-  }
 
   // producer cursors: the next B stage to request (p) and, on the 3-slot A ring, the next A stage (q = p + 1 stage)
   struct Cursor {
@@ -968,13 +953,6 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   g.a_bs = Aop->batch_stride; g.b_bs = Bop->batch_stride;
   g.M = M; g.N = N; g.K = K;
   g.tiles_m = 0; g.tiles_n = 0; g.split_k = split_k;
-  {
-    const char* st = getenv("DEVIT_GEMM_STAGGER");       // "cycles[,mode]"; read per launch so one process can A/B it
-    g.stagger_cycles = st ? atoi(st) : 0;
-    const char* comma = st ? strchr(st, ',') : nullptr;
-    g.stagger_mode = comma ? atoi(comma + 1) : 1;
-    if (g.stagger_cycles < 0 || g.stagger_cycles > 400000) g.stagger_cycles = 0;   // bound the in-kernel wait (< 0.25 ms)
-  }
   g.ep = *ep;
   // tile choice: 128x128 (4 waves, two workgroups per CU) or 256x256 (8 waves of 128x64, ping-pong schedule, one per CU)
   const int variant = (a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0);
