@@ -121,3 +121,17 @@ def test_call_sites_match_signatures():
                            f"declared with {len(_lib.SIGNATURES[name][1])}")
     assert seen > 40, f"only {seen} call sites found: the scan is not seeing the package"
     assert not bad, "\n".join(bad)
+
+
+def test_integration_doc_stub_matches_binding():
+    """INTEGRATION.md section B shows the ctypes structs a maintainer would copy.  Their field lists must be the real ones
+    (`_lib.Epilogue` / `_lib.Operand`, themselves held to the header above): a struct one field short makes the library
+    read the missing field from whatever follows it in memory (round 2: `dtype16` was appended to devit_epilogue)."""
+    from devit_amd import _lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for cls, real in (("Epilogue", _lib.Epilogue), ("Operand", _lib.Operand)):
+        m = re.search(r"class %s\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n" % cls, doc, re.S)
+        assert m, f"INTEGRATION.md no longer shows class {cls}"
+        names = re.findall(r'\("(\w+)",', m.group(1))
+        assert names == [f[0] for f in real._fields_], (cls, names)
+    assert f"all {len(_lib.SIGNATURES)} symbols" in doc, "INTEGRATION.md quotes a stale symbol count"

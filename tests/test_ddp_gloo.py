@@ -84,3 +84,41 @@ def test_bucketed_allreduce_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def _module_sync_worker(rank, world, port, q):
+    """The ensemble stage's synchronisation (ensemble.py:332-334 wraps both models in DistributedDataParallel; here
+    ddp.broadcast_module + ddp.allreduce_mean_): ranks that start different must end with rank 0's parameters and
+    buffers, and with the rank-mean of their gradients -- a None gradient (a frozen or unused parameter) is skipped."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)              # different init per rank, as the CLIs seed with seed + rank
+    model = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.BatchNorm1d(10), torch.nn.Linear(10, 3))
+    ddp.broadcast_module(model)
+    state = torch.cat([t.detach().reshape(-1).float() for t in list(model.parameters()) + list(model.buffers())])
+    both = [torch.zeros_like(state) for _ in range(world)]
+    dist.all_gather(both, state)
+    ok = torch.equal(both[0], both[1])
+    params = list(model.parameters())
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))      # rank-dependent: the mean is 1.5 (i + 1)
+    params[-1].grad = None                                         # skipped on every rank, must stay None
+    ddp.allreduce_mean_([p.grad for p in params])
+    ok = ok and params[-1].grad is None
+    for i, p in enumerate(params[:-1]):
+        ok = ok and torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1)), rtol=1e-6, atol=0)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_module_broadcast_and_gradient_mean_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_module_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res

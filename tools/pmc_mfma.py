@@ -30,7 +30,8 @@ def main():
                    "wait_any_frac": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
                    "wait_inst_frac": c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
                    "active_inst_frac": c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0)}
-    dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+>", k)]
+    dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+(, (true|false))?>", k)]   # (+ F16)
+    assert dom, "no gemm_kernel<.., A_KM=false, B_KM=false, ..> dispatch found: the kernel-name pattern is stale"
     busy = sum(tot[k]["SQ_VALU_MFMA_BUSY_CYCLES"] for k in dom)
     act = sum(tot[k]["GRBM_GUI_ACTIVE"] for k in dom) / 8.0 * 1024.0
     res = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "

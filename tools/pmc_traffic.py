@@ -33,7 +33,8 @@ def main():
                    "fetch_bytes_per_launch": ft[k] / max(fc[k], 1) * 1024 * 2,      # KiB -> B, x2 (gfx950)
                    "write_bytes_per_launch": wt[k] / max(wc[k], 1) * 1024}
     # the bench's dominant template: every gemm_kernel<.., A_KM=false, B_KM=false, ..> instantiation
-    dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+>", k)]
+    dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+(, (true|false))?>", k)]   # (+ F16)
+    assert dom, "no gemm_kernel<.., A_KM=false, B_KM=false, ..> dispatch found: the kernel-name pattern is stale"
     n = sum(rows[k]["launches"] for k in dom)
     fetch = sum(rows[k]["fetch_bytes_per_launch"] * rows[k]["launches"] for k in dom) / max(n, 1)
     write = sum(rows[k]["write_bytes_per_launch"] * rows[k]["launches"] for k in dom) / max(n, 1)
