@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--teacher-precision", default="bf16", choices=["f16", "bf16"],
                     help="16-bit type of the frozen teacher's forward: bf16 (default: the config BASELINE.json names) or f16 "
-                         "(same kernels and MFMA rate; teacher logits 1.1e-3 instead of 6.8e-3 from the fp32 reference -- "
-                         "around, not inside, the 1e-3 bar; reported as `teacher_dtype`)")
+                         "(same kernels; teacher logits 1.1e-3 instead of 6.8e-3 from the fp32 reference -- around, not inside, the "
+                         "1e-3 bar -- and the step 1.4 %% slower, same-box A/B; reported as `teacher_dtype`)")
     ap.add_argument("--classes", type=int, default=0, help="override the class count (default 25 at N=1, 250 at N>1)")
     ap.add_argument("--host-input", action="store_true",
                     help="PCIe-inclusive variant (DESIGN.md section 6, never the headline value): every step's batch starts "

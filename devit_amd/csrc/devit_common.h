@@ -100,7 +100,7 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 // ---- the second 16-bit storage type: IEEE f16 ---------------------------------------------------------
 // The frozen teacher's forward can run with f16 instead of bf16 operands and stored activations (11 significand bits
 // instead of 8: DeiT-B logits 1.1e-3 from the fp32 reference instead of 6.8e-3, profiles/r02_b_f16_localise.txt; same MFMA
-// rate; no gradients, so no loss scaling).  Fragments travel through LDS and registers as raw 16-bit lanes typed bf16x8;
+// rate per the ISA, the step measures 1.4 % slower; no gradients, so no loss scaling).  Fragments travel through LDS and registers as raw 16-bit lanes typed bf16x8;
 // only the MFMA opcode and the float -> 16-bit conversions differ.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;

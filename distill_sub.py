@@ -68,7 +68,7 @@ def get_args_parser():
     a('--neuron_shrinking', action='store_true', default=False); a('--head_shrinking', action='store_true', default=False)
     a('--synthetic', type=int, default=0, metavar='STEPS', help='train on STEPS random on-device batches per epoch')
     a('--teacher-precision', default='bf16', choices=['f16', 'bf16'],
-      help="16-bit type of the frozen teacher's forward (f16: teacher logits 1.1e-3 instead of 6.8e-3 from fp32, at the bf16 speed)")
+      help="16-bit type of the frozen teacher's forward (f16: teacher logits 1.1e-3 instead of 6.8e-3 from fp32; step 1.4 %% slower)")
     a('--no-teacher-lookahead', dest='teacher_lookahead', action='store_false',
       help='run the frozen teacher inside the step instead of one batch ahead (engine.TeacherLookahead)')
     return p
