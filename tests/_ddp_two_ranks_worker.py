@@ -1,0 +1,153 @@
+"""Worker of tests/test_gpu_ddp.py::test_two_ranks_share_one_gpu: one rank of a world-size-2 run of the REAL DEKD step
+(dedeit <- DeiT-B, C = 250 as in BASELINE config 4) with both ranks on cuda:0.
+
+Why: config 4's transport (RCCL over xGMI) needs two GPUs and the builder has one; NCCL refuses two ranks on one device.
+Everything else of the data-parallel path can run here for real: ranks that start with different weights and see different
+data, the initial broadcast, FlatParams / bf16 re-cast, the autograd nodes reporting parameters, BucketedGradReducer
+launching every bucket on its side stream during backward, 1/world folded into the fused optimizer kernel.  The exchange
+itself goes through gloo, staged through pinned host memory by a transport object injected into the reducer (the same
+hook the recording communicator of the one-rank test uses).  This is a correctness rehearsal, never a timing.
+
+Checks (any failure -> non-zero exit; rank 0 prints one JSON line):
+  A. after two optimizer steps the fp32 master weights are bit-identical on both ranks;
+  B. the mean gradient of step 0 equals the gradient of ONE process on the concatenated batch (drop_path 0);
+  C. every bucket left during backward, before finish();
+  D. the reducer's timing summary (allreduce_ms, overlap_frac) is produced.
+Launched as: python -m torch.distributed.run --nproc-per-node 2 ... tests/_ddp_two_ranks_worker.py"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class HostStagedGloo:
+    """Transport for BucketedGradReducer: in-place SUM over ranks of a CUDA fp32 view, through pinned host memory + gloo."""
+
+    def __init__(self, world):
+        self.world, self.calls = world, 0
+
+    def all_reduce(self, view, stream=None):
+        host = torch.empty(view.shape, dtype=view.dtype, pin_memory=True)
+        host.copy_(view, non_blocking=True)            # on the reducer's side stream (current inside its `with`)
+        (stream or torch.cuda.current_stream()).synchronize()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        view.copy_(host, non_blocking=True)
+        self.calls += 1
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert world == 2
+    torch.cuda.set_device(0)                           # both ranks on the one GPU
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import devit_amd
+    from devit_amd import ddp, engine, losses, optim
+
+    C, B = 250, 8
+    torch.manual_seed(100 + rank)                      # ranks start different (the CLIs seed with seed + rank)
+    student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.0).to(dev).train()
+    torch.manual_seed(1)                               # the frozen teacher is the same file on every rank
+    teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
+    for p in teacher.parameters():
+        p.requires_grad_(False)
+
+    flat = ddp.FlatParams(student)
+    before = flat.flat.detach().clone()
+    try:                                               # the product call; gloo builds without device support raise here
+        ddp.broadcast_parameters(flat)
+        bcast = "ddp.broadcast_parameters (gloo, device tensor)"
+    except Exception as e:                             # noqa: BLE001 -- report which path ran, do not hide it
+        w = flat.flat.detach().cpu()
+        dist.broadcast(w, src=0)
+        flat.flat.copy_(w)
+        bcast = f"host-staged broadcast ({type(e).__name__} from the device-tensor call)"
+    changed = not torch.equal(before, flat.flat)
+    assert changed == (rank != 0), "rank 0 keeps its weights, every other rank must receive them"
+    flat.attach_bf16(student)
+    assert torch.equal(flat.flat16, flat.flat.to(torch.bfloat16)), "bf16 GEMM copies must be cast AFTER the broadcast"
+    w0 = flat.flat.detach().clone()
+
+    comm = HostStagedGloo(world)
+    reducer = ddp.BucketedGradReducer(flat, comm=comm).attach(student)
+    reducer.timing = True
+    assert reducer.world == 2 and len(reducer.buckets) >= 4
+    opt = optim.FlatAdamW(flat, lr=5e-4, weight_decay=0.0, max_norm=1.0, ema_decay=0.99996)
+
+    def batch(r):
+        g = torch.Generator(device=dev).manual_seed(1234 + r)
+        img = torch.randn((B, 3, 224, 224), generator=g, device=dev)
+        y = torch.randint(0, C, (B,), generator=g, device=dev)
+        soft = torch.full((B, C), 0.1 / C, device=dev).scatter_(1, y[:, None], 0.9 + 0.1 / C)
+        return img, soft
+
+    img, soft = batch(rank)
+    mean_grad = loss0 = None
+    for it in range(2):
+        opt.zero_grad()
+        out = engine.distill_forward(student, teacher, img, soft)
+        out["loss"].backward()
+        assert comm.calls == (it + 1) * len(reducer.buckets), \
+            f"C: {comm.calls - it * len(reducer.buckets)} of {len(reducer.buckets)} buckets left during backward"
+        order = reducer.finish()
+        assert order == list(range(len(reducer.buckets))), order
+        assert flat.grad_scale == 0.5
+        if it == 0:
+            mean_grad = (flat.flat_grad * flat.grad_scale).detach().clone()
+            loss0 = out["loss"].detach().clone()
+        opt.step()
+    timing = reducer.timing_summary()
+    assert timing is not None and timing[0] > 0 and 0.0 <= timing[1] <= 1.0, timing
+    torch.cuda.synchronize()
+
+    # A. identical masters on both ranks (bitwise: same reduced gradients through the same kernel)
+    mine = flat.flat.detach().cpu()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert torch.equal(both[0], both[1]), "A: ranks diverged"
+    assert not torch.equal(mine, w0.cpu()), "the optimizer steps changed nothing"
+    losses_ = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(losses_, loss0.cpu().reshape(1))
+
+    result = None
+    if rank == 0:
+        # B. one process, concatenated batch, the broadcast weights: its gradient is what DDP's mean must equal
+        torch.manual_seed(100)
+        ref = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.0).to(dev).train()
+        fref = ddp.FlatParams(ref)
+        fref.flat.copy_(w0)
+        fref.attach_bf16(ref)
+        i0, s0 = batch(0)
+        i1, s1 = batch(1)
+        fref.zero_grad()                               # attaches every p.grad as a view of fref.flat_grad
+        out = engine.distill_forward(ref, teacher, torch.cat([i0, i1]), torch.cat([s0, s1]))
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        g_ref, g_dp = fref.flat_grad.double(), mean_grad.double()
+        assert float(g_ref.norm()) > 0, "the reference backward wrote no gradient into its flat buffer"
+        rel = float((g_dp - g_ref).norm() / g_ref.norm())
+        worst = 0.0
+        for i, (p, o) in enumerate(zip(fref.params, fref.offsets)):
+            a, b = g_dp[o:o + p.numel()].norm(), g_ref[o:o + p.numel()].norm()
+            if float(b) > 0:
+                worst = max(worst, abs(float(a) - float(b)) / float(b))
+        loss_dp = float((losses_[0] + losses_[1]) / 2)
+        loss_rel = abs(loss_dp - float(out["loss"])) / abs(float(out["loss"]))
+        result = {"world": world, "broadcast": bcast, "buckets": len(reducer.buckets), "params": len(flat.params),
+                  "grad_rel_l2_vs_single_process": rel, "worst_param_grad_norm_rel": worst, "loss_rel": loss_rel,
+                  "allreduce_ms": round(timing[0], 3), "overlap_frac": round(timing[1], 3),
+                  "transport": "gloo through pinned host memory (RCCL needs two GPUs)"}
+        assert rel < 2e-3 and worst < 5e-3 and loss_rel < 1e-4, result
+    dist.barrier()
+    if rank == 0:
+        print("DDP_REHEARSAL " + json.dumps(result), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,3 +120,36 @@ def test_weight_decay_groups_match_torch_adamw():
     for n, p in m.named_parameters():
         d = float((p.detach() - params[n].detach()).abs().max())
         assert d < 1e-6, (n, d, float((p.detach() - ref[n]).abs().max()))
+
+
+def test_two_ranks_share_one_gpu():
+    """A world-size-2 run of the real DEKD step on hardware, as far as one GPU allows (BASELINE config 4: dedeit <- DeiT-B,
+    C = 250, DDP).  Two ranks, both on cuda:0, different initial weights and different data; exchange through gloo (RCCL
+    refuses two ranks on one device).  The worker (tests/_ddp_two_ranks_worker.py) asserts identical masters on both ranks
+    after two steps, the mean gradient against one process on the concatenated batch, every bucket launched during
+    backward, and the reducer's timing summary; this test checks it ran to the end on both ranks."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "tests", "_ddp_two_ranks_worker.py")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DDP_REHEARSAL ")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    res = json.loads(lines[0][len("DDP_REHEARSAL "):])
+    assert res["world"] == 2 and res["params"] == 155 and res["buckets"] >= 4
+    out = os.path.join(root, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "ddp_two_ranks_one_gpu.json"), "w") as f:
+        json.dump(res, f, indent=1)
