@@ -141,8 +141,12 @@ def main():
         result = {"world": world, "broadcast": bcast, "buckets": len(reducer.buckets), "params": len(flat.params),
                   "grad_rel_l2_vs_single_process": rel, "worst_param_grad_norm_rel": worst, "loss_rel": loss_rel,
                   "allreduce_ms": round(timing[0], 3), "overlap_frac": round(timing[1], 3),
-                  "transport": "gloo through pinned host memory (RCCL needs two GPUs)"}
-        assert rel < 2e-3 and worst < 5e-3 and loss_rel < 1e-4, result
+                  "transport": "gloo through pinned host memory (RCCL needs two GPUs)",
+                  "note": "allreduce_ms / overlap_frac only show that the timing path runs: this transport blocks the host per "
+                          "bucket, so every bucket ends before the rest of backward is enqueued -- not a statement about RCCL"}
+        # measured on MI355X: 1.2e-7 / 3.5e-8 / 6e-8 (fp32 round-off: per-row kernels give identical activations, only the
+        # weight-gradient summation order differs); bars at ~100x that
+        assert rel < 1e-5 and worst < 1e-5 and loss_rel < 1e-5, result
     dist.barrier()
     if rank == 0:
         print("DDP_REHEARSAL " + json.dumps(result), flush=True)

@@ -129,6 +129,7 @@ def test_two_ranks_share_one_gpu():
     after two steps, the mean gradient against one process on the concatenated batch, every bucket launched during
     backward, and the reducer's timing summary; this test checks it ran to the end on both ranks."""
     import json
+    import os
     import socket
     import subprocess
     import sys
