@@ -28,8 +28,11 @@ def ints(shape, lo, hi, dev, seed):
     return torch.randint(lo, hi + 1, shape, generator=g).to(dev)
 
 
-@pytest.mark.parametrize("Nout,K,kind,bkm", [(1152, 384, "f32", 0), (2304, 768, "bf16", 0), (768, 3072, "res", 0),
-                                             (384, 1536, "f32", 1), (1536, 384, "bf16", 0)])
+# The last three shapes are the teacher's fc2 (residual epilogue without a DropPath scale, with the bf16 branch copy), the same
+# shape with a plain fp32 store, and fc1's shape: 256x256-tile launches of 2.32 and 9.28 rounds on 256 CUs.
+@pytest.mark.parametrize("Nout,K,kind,bkm", [
+    (1152, 384, "f32", 0), (2304, 768, "bf16", 0), (768, 3072, "res", 0), (384, 1536, "f32", 1), (1536, 384, "bf16", 0),
+    (768, 3072, "res_noscale", 0), (768, 3072, "f32", 0), (3072, 768, "bf16", 0)])
 def test_gemm_exact_integers_full_size(dev, Nout, K, kind, bkm):
     """A in {-3..3}, W in {-1,0,1}: |sum| <= 3 K < 2^14, exact in fp32 and (for the bf16 store: values clipped to
     |x| <= 256 by construction of a sparse W) in bf16 -- every output tile of the persistent launch, bit for bit."""
@@ -49,6 +52,14 @@ def test_gemm_exact_integers_full_size(dev, Nout, K, kind, bkm):
         out = torch.empty((M, Nout), dtype=BF16, device=dev)
         ops.gemm(a, K, 0, w, Nout if bkm else K, bkm, M, Nout, K, kind=L.EPI_STORE_BF16, out=out, ldc=Nout)
         assert torch.equal(out.float(), ref)
+    elif kind == "res_noscale":                 # the teacher's fc2 (eval: no DropPath scale), bf16 copy of the branch too
+        res = ints((M, Nout), -50, 50, dev, 4).float()
+        out = torch.empty((M, Nout), dtype=F32, device=dev)
+        copy = torch.empty((M, Nout), dtype=BF16, device=dev)
+        ops.gemm(a, K, 0, w, K, 0, M, Nout, K, kind=L.EPI_RESIDUAL_F32, out=out, ldc=Nout, res=res, aux=copy)
+        assert torch.equal(out, res + ref)
+        exact = ref.abs() <= 256                # integers up to 256 are bf16 values: the branch copy is exact there
+        assert torch.equal(copy.float()[exact], ref[exact]) and float(exact.float().mean()) > 0.99
     else:                                       # residual epilogue with a per-image scale in {0, 1, 2}
         res = ints((M, Nout), -50, 50, dev, 4).float()
         rs = ints((B,), 0, 2, dev, 5).float()
