@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0); torch.cuda.set_device(0); B, C = 64, 250
 student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None).to(dev).train()
 teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
 for p in teacher.parameters(): p.requires_grad_(False)
-flat = ddp.FlatParams(student).attach_bf16(student); ddp.broadcast_parameters(flat)
+flat = ddp.FlatParams(student); ddp.broadcast_parameters(flat); flat.attach_bf16(student)   # broadcast first, then cast the bf16 copies
 reducer = ddp.BucketedGradReducer(flat).attach(student); reducer.world = 2
 opt = optim.FlatAdamW(flat, lr=1e-4, weight_decay=0.0, max_norm=1.0, ema_decay=0.99996)
 crit = losses.DistillLoss(losses.SoftTargetCrossEntropy(), "hard", 0.5, 1.0)
@@ -21,7 +21,7 @@ look = engine.TeacherLookahead(teacher); look.submit(img)
 for it in range(4):
     opt.zero_grad(); t = look.take(img); look.submit(img)
     out = engine.distill_forward(student, teacher, img, soft, criterion=crit, teacher_outputs=t)
-    out["loss"].backward(); n = len(reducer.handles); reducer.finish(); opt.step()
+    out["loss"].backward(); n = sum(reducer.launched); reducer.finish(); opt.step()
     torch.cuda.synchronize()
     print(f"step {it}: loss {float(out['loss']):.5f}, {len(reducer.buckets)} buckets, {n} all-reduces launched during backward", flush=True)
 assert torch.isfinite(flat.flat).all()
