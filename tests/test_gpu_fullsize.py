@@ -273,3 +273,40 @@ def test_distill_step_bf16_vs_f32_full_size(dev):
         bar = 7e-2 if n.startswith(("patch_embed", "pos_embed", "cls_token", "dist_token")) else (3e-2 if g32[n].ndim > 1 else 4e-2)
         assert chk(e, bar), f"{n}: gradient rel-to-max err {e:.3e}"
     print("bs-256 bf16 vs f32 gradient slices, rel-to-max:", {k: round(v, 5) for k, v in worst.items()})
+
+
+def test_ensemble_config5_full_size(dev):
+    """BASELINE config 5 at its size: four `dedeit` sub-models (250 classes each, shrink_ratio 0.3 head / neuron gates) +
+    EnsMLP -> 1000 classes, bs 256, inference (ensemble.py; models/ensemble_models.py:32-40).  The 4 x 25-class, bs-4 form is
+    held to the reference golden (test_gpu_model.py::test_ensemble_vs_golden); here, where a CPU run would take minutes:
+      * the physically shrunk models (shrink.compact) compute the masked models' function,
+      * uncompact restores the masked outputs bit for bit,
+      * the first 8 images of the bs-256 batch give what a bs-8 batch of the same images gives (every kernel is row- or
+        image-local and a tile's K order does not depend on M), which ties this size to the oracle-checked small cases."""
+    import devit_amd
+    from devit_amd import shrink
+    from devit_amd.ensemble_models import EnsMLP, MultiViT
+    torch.manual_seed(5)
+    multi = MultiViT("dedeit", drop=0, drop_path=0.0, num_classes_list=[250] * 4, num_div=4).to(dev).eval()
+    ens = EnsMLP("dedeit", 1000, 384, [250] * 4, 768).to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    for bb in multi.backbones:
+        for blk in bb.blocks:
+            hm = torch.ones(6); hm[torch.randperm(6, generator=g)[:2]] = 0
+            nm = torch.ones(1536); nm[torch.randperm(1536, generator=g)[:461]] = 0
+            blk.attn.gate, blk.mlp.gate = hm, nm
+    img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(6)).to(dev)
+    with torch.no_grad():
+        masked = ens(multi(img))
+        small = ens(multi(img[:8].contiguous()))
+        assert masked.shape == (B, 1000) and bool(torch.isfinite(masked).all())
+        assert torch.equal(masked[:8], small), "a batch slice must not depend on the batch it is computed in"
+        rep = shrink.compact(multi)
+        assert len(rep) == 4 * 12 and all(hr in (4, 6) and nr == 1152 for _, hr, _, nr in rep)
+        comp = ens(multi(img))
+        shrink.uncompact(multi)
+        again = ens(multi(img))
+    assert torch.equal(again, masked)
+    err = float((comp.float() - masked.float()).abs().max() / masked.float().abs().max())
+    agree = float((comp.argmax(1) == masked.argmax(1)).float().mean())
+    assert err < 1e-2 and agree >= 0.99, (err, agree)      # same bf16 path with the zero terms left out
