@@ -92,8 +92,23 @@ def cpu_baseline(seconds):
         if time.time() - t0 > seconds or n >= 20:
             break
     dt = time.time() - t0
+    # BASELINE configs[0] (the reference's own CPU-runnable case): `dedeit` single sub-model eval forward, bs 8
+    st_eval = {k: v.detach() for k, v in st_s.items()}
+    m, f0 = 0, None
+    with torch.no_grad():
+        while True:
+            O.forward(st_eval, gs, img, training=False)
+            if f0 is None:
+                f0 = time.time()
+                continue
+            m += 1
+            if time.time() - f0 > min(5.0, seconds) or m >= 40:
+                break
+    fdt = time.time() - f0
     return {"value": round(8 * n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} fp32 DEKD steps (student fwd+bwd, DeiT-B teacher fwd, losses) at bs 8, no optimizer"}
+            "sample": f"{n} fp32 DEKD steps (student fwd+bwd, DeiT-B teacher fwd, losses) at bs 8, no optimizer",
+            "config1_forward": {"value": round(8 * m / fdt, 2), "unit": "images/sec",
+                                "sample": f"{m} fp32 `dedeit` eval forwards at bs 8 (BASELINE configs[0])"}}
 
 
 def pmc_traffic():
