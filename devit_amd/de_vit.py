@@ -395,7 +395,9 @@ class VisionTransformer(nn.Module):
 
     def _features(self, x, output_qkv, output_att, output_emb, output_encoders, with_heads):
         if self.resize_dim is not None:
-            raise NotImplementedError("resize_dim (--distillation-token) is outside the DEKD hot path")
+            raise NotImplementedError("resize_dim (--distillation-token) is not built: the reference's own model cannot run it "
+                                      "(models/de_vit.py:276 applies resize_att_mlp to None unless output_att, :313-314 to the distilled "
+                                      "(cls, dist) tuple; train_subdata.py:253 unpacks the returned dict as a pair) -- DESIGN.md section 9")
         x = self.embed(x)
         emb = x
         xo, qkvs, atts, encs = run_blocks(list(self.blocks), x, self.training, output_qkv, output_att, output_encoders,

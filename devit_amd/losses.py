@@ -117,7 +117,9 @@ class DistillationLoss(nn.Module):
         super().__init__()
         assert distillation_type in ['none', 'soft', 'hard']
         if distill_token:
-            raise NotImplementedError("DistillationLoss(distill_token=True): resize_dim models are outside the DeViT path")
+            raise NotImplementedError("DistillationLoss(distill_token=True) is not built: utils/losses.py:106-108 unpacks the teacher's "
+                                      "return value as (token, logits), which the repository's own model never returns (it returns a "
+                                      "dict) -- DESIGN.md section 9")
         self.base_criterion, self.teacher_model = base_criterion, teacher_model
         self.distillation_type, self.alpha, self.tau = distillation_type, alpha, tau
         # LabelSmoothingCrossEntropy (train_subdata.py:411-416 without mixup) == soft-target CE on smoothed one-hot rows
