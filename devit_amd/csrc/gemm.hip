@@ -939,8 +939,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   if (ep->kind == DEVIT_EPI_DGELU_BF16) DEVIT_CHECK(ep->aux_in != nullptr, DEVIT_ERR_ARG, "DGELU: aux_in");
   if (ep->kind == DEVIT_EPI_ATOMIC_F32 && ep->aux)
     DEVIT_CHECK(batch == 1, DEVIT_ERR_ARG, "ATOMIC: the fused row sums of A (aux) need batch == 1");
-  DEVIT_CHECK(ep->exact_gelu == 0, DEVIT_ERR_ARG, "devit_gemm_bf16: exact_gelu=1 (erff) is not built; the fused GELU uses a "
-              "1.5e-7-accurate erf");
+  DEVIT_CHECK(ep->exact_gelu == 0, DEVIT_ERR_ARG, "devit_gemm_bf16: exact_gelu=1 (erff) is not built; the fused GELU is the "
+              "fitted x * sigmoid(x * P(x^2)) form, |error| <= 2.6e-5 (devit_common.h); precision=\"f32\" uses erff");
 
   const bool f16 = ep->dtype16 != 0;
   DEVIT_CHECK(ep->dtype16 == 0 || ep->dtype16 == 1, DEVIT_ERR_ARG, "devit_gemm_bf16: dtype16 must be 0 (bf16) or 1 (f16)");
