@@ -40,9 +40,8 @@ __device__ __forceinline__ bf16x8 pbuf_tr_frag(const char* buf, int k0, int c0, 
   return cat8(lds_tr_read(a), lds_tr_read(a + 4 * PSTRIDE * 2));
 }
 
-// Rows [0, KROWS) of a strided [N][64] bf16 matrix -> an LDS image (rows >= N zero), in two halves so that a kernel
-// can issue the global loads of ALL its images before the first LDS write: one exposed HBM latency per workgroup
-// instead of one per image.
+// Rows [0, KROWS) of a strided [N][64] bf16 matrix -> registers -> an LDS image (rows >= N zero).  Only the backward's dO / O
+// rows still travel this way (delta needs them in registers); every other image arrives by LDS-DMA, see dma_image().
 template <int NT>
 struct RowRegs {
   static constexpr int ITERS = (KROWS * 8 + NT - 1) / NT;
@@ -68,6 +67,23 @@ __device__ __forceinline__ void put_image(char* img, const RowRegs<NT>& r, float
       for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * mul);
     }
     if (row < KROWS) *(bf16x8*)(img + img_off(row, c)) = v;
+  }
+}
+
+// Rows [0, KROWS) of a strided [N][64] 16-bit matrix -> an LDS image by LDS-DMA: one wave-instruction moves 8 rows x 128 B
+// (1 KiB) into consecutive LDS bytes, so the image's chunk swizzle goes on the per-lane SOURCE address (lane l of slab s
+// writes row 8 s + l / 8, physical chunk l % 8, which must hold logical chunk (l % 8) ^ swizzle(row)).  Rows >= N cannot
+// be zero-filled by a DMA: they repeat row N - 1 (finite values; every use of a padded key or query is masked to P = 0).
+template <int NWAVES>
+__device__ __forceinline__ void dma_image(char* img, const __bf16* src, size_t row_stride, int N, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < (KROWS / 8 + NWAVES - 1) / NWAVES; ++it) {
+    const int slab = wave + it * NWAVES;
+    if (slab < KROWS / 8) {
+      const int row = slab * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+      const __bf16* g = src + (size_t)min(row, N - 1) * row_stride + c * 8;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(img + slab * 1024), 16, 0, 0);
+    }
   }
 }
 
@@ -114,13 +130,11 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
       qall[it][kk] = (wave + it * FWD_WAVES < ntile && q_ < N) ? *(const bf16x8*)(qbase + (size_t)q_ * rs + kk * 32 + g * 8) : z;
     }
   }
-  {
-    RowRegs<FWD_WAVES * 64> kr, vr;
-    fetch_rows(kr, qbase + D, rs, N, tid);
-    fetch_rows(vr, qbase + 2 * D, rs, N, tid);
-    put_image(k_img, kr, 1.0f, tid);
-    put_image(v_img, vr, 1.0f, tid);
-  }
+  // K and V images by LDS-DMA: no register round trip, no ds_write pass (forward -6 ... -10 % against register staging, same
+  // box, profiles/r02_l_attention_dma_prologue.txt); the Q fragments above go straight to registers in MFMA layout
+  dma_image<FWD_WAVES>(k_img, qbase + D, rs, N, wave, lane);
+  dma_image<FWD_WAVES>(v_img, qbase + 2 * D, rs, N, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share has landed; the barrier covers the others'
   __syncthreads();
   const int tmask = N >> 4;                          // first key tile that contains a key >= N
 
@@ -244,13 +258,14 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
   const __bf16* obase = a.out + (size_t)b * N * D + h * HD;
 
   {
-    // every global load of the prologue (four images, O rows and lse for delta) is issued before the first LDS write
+    // Q, K, V images by LDS-DMA (issued first: they are in flight while the rest of the prologue runs); dO (scaled by the
+    // head gate), the O rows and lse go through registers because delta[q] = sum_d dO[q][d] O[q][d] needs them there
     constexpr int NT = BWD_WAVES * 64;
-    RowRegs<NT> qr, kr, vr, dr, orr;
+    dma_image<BWD_WAVES>(q_img, qbase, rs, N, wave, lane);
+    dma_image<BWD_WAVES>(k_img, qbase + D, rs, N, wave, lane);
+    dma_image<BWD_WAVES>(v_img, qbase + 2 * D, rs, N, wave, lane);
+    RowRegs<NT> dr, orr;
     float ls[RowRegs<NT>::ITERS];
-    fetch_rows(qr, qbase, rs, N, tid);
-    fetch_rows(kr, qbase + D, rs, N, tid);
-    fetch_rows(vr, qbase + 2 * D, rs, N, tid);
     fetch_rows(dr, dobase, (size_t)D, N, tid);
     fetch_rows(orr, obase, (size_t)D, N, tid);
 #pragma unroll
@@ -258,13 +273,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
       const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
       ls[it] = (row < N && c == 0) ? a.lse[((size_t)b * a.H + h) * N + row] * 1.4426950408889634f : 0.f;
     }
-    // zero both dS^T buffers once: key rows of tiles that are never written (>= ntile) must read as 0 in dQ
     for (int i = tid; i < 2 * DST_BYTES / 16; i += NT) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    put_image(q_img, qr, 1.0f, tid);
-    put_image(k_img, kr, 1.0f, tid);
-    put_image(v_img, vr, 1.0f, tid);
-    // lse (log2 domain) and delta[q] = sum_d dO[q][d] O[q][d] (unscaled dO: O is the post-gate output): 8 lanes per row,
-    // one 16-byte chunk each, from the registers that also fill the dO image
 #pragma unroll
     for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
       const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
@@ -280,6 +289,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
       }
     }
     put_image(do_img, dr, gate, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
 
