@@ -66,14 +66,32 @@ def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3)
     cls_loss = criterion(outputs=logits, teacher_outputs=teacher_logits, labels=targets)   # :79
     tl, sl = len(teacher_qkvs), len(qkvs)
     assert tl % sl == 0, 'The number of student layer can not be divisible by the number of teacher layer'
-    q_loss, k_loss, v_loss = losses.relation_losses_packed(qkvs[sl // 2 - 1], teacher_qkvs[tl // 2 - 1])  # :91-100
-    q_loss, k_loss, v_loss = q_loss / sl, k_loss / sl, v_loss / sl                  # :102-104
-    loss = cls_loss + float(gama[0]) * q_loss + float(gama[1]) * k_loss + float(gama[2]) * v_loss   # :105-106
+    rel3 = losses.relation_losses_vector(qkvs[sl // 2 - 1], teacher_qkvs[tl // 2 - 1])     # :91-100, as one [q, k, v] tensor
+    if rel3 is not None:
+        # :102-106 on the vector: total = cls + sum_j (gama_j / sl) loss_j (one dot + one add; backward one multiply) and the
+        # three logged values as views of loss / sl -- the scalar form costs ~25 tiny kernels per step around the same numbers
+        scaled = rel3 / sl
+        q_loss, k_loss, v_loss = scaled[0], scaled[1], scaled[2]
+        loss = cls_loss + torch.dot(rel3, _relation_weights(gama, sl, rel3.device))
+    else:
+        q_loss, k_loss, v_loss = losses.relation_losses_packed(qkvs[sl // 2 - 1], teacher_qkvs[tl // 2 - 1])
+        q_loss, k_loss, v_loss = q_loss / sl, k_loss / sl, v_loss / sl                  # :102-104
+        loss = cls_loss + float(gama[0]) * q_loss + float(gama[1]) * k_loss + float(gama[2]) * v_loss   # :105-106
     return dict(loss=loss, cls_loss=cls_loss, q_loss=q_loss, k_loss=k_loss, v_loss=v_loss, logits=logits,
                 teacher_logits=teacher_logits)
 
 
 _side_stream = {}
+_rel_w = {}
+
+
+def _relation_weights(gama, layers, device):
+    """[gama_q, gama_k, gama_v] / layers as a cached device tensor."""
+    key = (float(gama[0]), float(gama[1]), float(gama[2]), int(layers), str(device))
+    w = _rel_w.get(key)
+    if w is None:
+        w = _rel_w[key] = torch.tensor([key[0] / layers, key[1] / layers, key[2] / layers], dtype=torch.float32, device=device)
+    return w
 
 
 def _teacher_forward(teacher_model, samples):

@@ -67,6 +67,22 @@ def relation_losses_packed(student_qkv, teacher_qkv):
     return losses[0], losses[1], losses[2]
 
 
+def relation_losses_vector(student_qkv, teacher_qkv):
+    """The same three losses as ONE tensor [q, k, v] (or None when the inputs are not the packed qkv views of the HIP
+    models).  engine.distill_forward forms the total on this vector: three `select`s of it would cost three
+    select_backward kernels plus two accumulations in backward just to rebuild the 3-vector gradient."""
+    sp, tp = _packed_of(student_qkv[0]), _packed_of(teacher_qkv[0])
+    if sp is None or tp is None:
+        return None
+    (s_buf, B, N, Hs), (t_buf, Bt, Nt, Ht) = sp, tp
+    assert (B, N) == (Bt, Nt)
+    hd_s, hd_t = s_buf.shape[1] // (3 * Hs), t_buf.shape[1] // (3 * Ht)
+    if s_buf.dtype == torch.float32:          # exact-fp32 parity path
+        from . import ops_f32
+        return ops_f32.RelationLossF32Fn.apply(s_buf, t_buf.detach().float(), B, N, hd_s, hd_t)
+    return ops.RelationLossFn.apply(s_buf, t_buf.detach(), B, N, hd_s, hd_t)
+
+
 def _repack(feature):
     """[B, H, N, hd] (any strides) -> packed bf16 [pad(B*N) + 128, 3*H*hd] with the feature in every component."""
     B, H, N, hd = feature.shape

@@ -177,6 +177,17 @@ def cast_bf16(src, dst=None, f16=False):
     return dst
 
 
+_ONES1 = {}
+
+
+def _ones1(dev):
+    """A cached fp32 [1.0] on `dev` (the ones-vector operand of the bias-gradient sgemm calls)."""
+    t = _ONES1.get(dev)
+    if t is None:
+        t = _ONES1[dev] = torch.ones(1, dtype=F32, device=dev)
+    return t
+
+
 def grad_buf(p):
     """fp32 accumulation buffer of a parameter (== param.grad, zero-initialised on first use)."""
     if p.grad is None:
@@ -754,7 +765,7 @@ class HeadsFn(torch.autograd.Function):
             sgemm_small(dl, Cn, 1, w, 1, D, None, dt[:, j], ntok * D, B, D, Cn, accumulate=True)
             # dw[C, D] += dl^T @ tok_j ; db += colsum(dl)
             sgemm_small(dl, 1, Cn, tok[:, j], 1, ntok * D, None, grad_buf(w), D, Cn, D, B, accumulate=True)
-            ones = torch.ones(1, dtype=F32, device=dev)
+            ones = _ones1(dev)
             sgemm_small(dl, 1, Cn, ones, 0, 0, None, grad_buf(b), 1, Cn, 1, B, accumulate=True)
         dx = torch.zeros((B, T, D), dtype=F32, device=dev)
         layernorm_bwd(dt, True, x.view(B * T, D), B * ntok, D, mean, rstd, norm_w, None, dx.view(B * T, D), None, None,
