@@ -2,10 +2,10 @@
 
 PyTorch is plumbing here: it owns device memory and streams, autograd stitches the hand-written
 forward/backward kernel sequences together.  Every GEMM, attention, LayerNorm, loss and optimizer kernel is behind the
-C ABI; what torch itself still launches per step is glue -- about 40 small elementwise kernels (zero-fills of fresh
-buffers, the sum of the five loss terms and the gradient adds autograd makes where two paths meet, scalar scales, the
-DropPath mask draw: rand / floor / div) and ~25 runtime copies, 0.33 ms of the 29.7 ms serialized step
-(profiles/r02_e_bench_serial_kernel_stats.csv).
+C ABI; what torch itself still launches per step is glue -- a few dozen small elementwise kernels (zero-fills of fresh
+buffers, combining the loss terms, the gradient adds autograd makes where two paths meet, scalar scales, the DropPath
+mask draw: rand / floor / div) and ~25 runtime copies, about 0.3 ms of the 29.7 ms serialized step (measured as 0.33 ms
+in profiles/r02_e_bench_serial_kernel_stats.csv, before the loss total moved onto the relation-loss vector).
 
 Layout conventions
   * token rows: M = B * N; every bf16 activation that feeds a GEMM lives in a buffer whose row count is
