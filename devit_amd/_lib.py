@@ -77,6 +77,8 @@ SIGNATURES = {
                              _I, _I, _I, _F, _P]),
     "devit_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "devit_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "devit_attn_fwd_rows": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "devit_attn_bwd_rows": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "devit_im2row_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "devit_mix_im2row_bf16": (_I, [_P, _P, _P, _I, _I, C.c_double, _I, _I, _I, _I, _P]),
     "devit_mix_targets": (_I, [_P, _P, _I, _I, C.c_double, C.c_double, _P]),

@@ -87,12 +87,18 @@ __device__ __forceinline__ void dma_image(char* img, const __bf16* src, size_t r
   }
 }
 
+// Query side and key side are described separately: the packed form (devit_attn_fwd) points all three at one qkv buffer
+// with NQ == N; the rows form (devit_attn_fwd_rows) reads NQ <= N query rows per image from a buffer of their own -- the
+// last block of a model whose caller consumes only the class / distillation tokens (models/de_vit.py:286-288).
 struct AttnFwdArgs {
-  const __bf16* qkv;
-  __bf16* out;
-  float* lse;
+  const __bf16* q;      // [B*NQ][q_rs], feature h*64 + e
+  const __bf16* k;      // [B*N][kv_rs]
+  const __bf16* v;
+  __bf16* out;          // [B*NQ][H*64]
+  float* lse;           // [B][H][NQ]
   const float* head_gate;
-  int B, N, H;
+  int B, N, NQ, H;
+  int q_rs, kv_rs;
   float scale;
 };
 
@@ -110,12 +116,12 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int D = a.H * HD, N = a.N;
-  const size_t rs = (size_t)3 * D;
-  const __bf16* qbase = a.qkv + (size_t)b * N * rs + h * HD;
+  const int D = a.H * HD, N = a.N, NQ = a.NQ;
+  const size_t rs = (size_t)a.q_rs, krs = (size_t)a.kv_rs;
+  const __bf16* qbase = a.q + (size_t)b * NQ * rs + h * HD;
   const float c2 = a.scale * 1.4426950408889634f;  // scores in log2 domain
   const float gate = a.head_gate ? a.head_gate[h] : 1.0f;
-  const int ntile = (N + 15) >> 4;
+  const int ntile = (NQ + 15) >> 4;                  // query tiles
   const int g = lane >> 4, lc = lane & 15;
   const int tq = (lane >> 2) & 3, tp = lane & 3;     // transposed-read row / column-quad of this lane
   constexpr int QT = (MAXT + FWD_WAVES - 1) / FWD_WAVES;   // query tiles per wave
@@ -127,13 +133,13 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qall[it][kk] = (wave + it * FWD_WAVES < ntile && q_ < N) ? *(const bf16x8*)(qbase + (size_t)q_ * rs + kk * 32 + g * 8) : z;
+      qall[it][kk] = (wave + it * FWD_WAVES < ntile && q_ < NQ) ? *(const bf16x8*)(qbase + (size_t)q_ * rs + kk * 32 + g * 8) : z;
     }
   }
   // K and V images by LDS-DMA: no register round trip, no ds_write pass (forward -6 ... -10 % against register staging, same
   // box, profiles/r02_l_attention_dma_prologue.txt); the Q fragments above go straight to registers in MFMA layout
-  dma_image<FWD_WAVES>(k_img, qbase + D, rs, N, wave, lane);
-  dma_image<FWD_WAVES>(v_img, qbase + 2 * D, rs, N, wave, lane);
+  dma_image<FWD_WAVES>(k_img, a.k + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
+  dma_image<FWD_WAVES>(v_img, a.v + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share has landed; the barrier covers the others'
   __syncthreads();
   const int tmask = N >> 4;                          // first key tile that contains a key >= N
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
     s[MAXT] = (f32x4){0.f, 0.f, 0.f, 0.f};           // keys 208..223
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    if (a.lse && g == 0 && q < N) a.lse[((size_t)b * a.H + h) * N + q] = (mxs + log2f(sum)) * 0.6931471805599453f;
+    if (a.lse && g == 0 && q < NQ) a.lse[((size_t)b * a.H + h) * NQ + q] = (mxs + log2f(sum)) * 0.6931471805599453f;
 
     f32x4 o[4];
 #pragma unroll
@@ -192,9 +198,9 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
         o[dt] = mfma16t<F16>(vf, pf, o[dt]);         // O^T[d][q] += V^T[d][key] P^T[key][q]
       }
     }
-    if (q < N) {
+    if (q < NQ) {
       const float sc = gate / sum;
-      __bf16* orow = a.out + ((size_t)b * N + q) * D + h * HD + g * 4;
+      __bf16* orow = a.out + ((size_t)b * NQ + q) * D + h * HD + g * 4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         *(bf16x4*)(orow + dt * 16) = cvt4<F16>(o[dt] * sc);
@@ -212,14 +218,21 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
 // dQ^T = K^T dS^T.  Every gradient leaves as 8-byte (4 x bf16) stores along d.
 // ------------------------------------------------------------------------------------------
 struct AttnBwdArgs {
-  const __bf16* qkv;
-  const __bf16* out;    // forward output (post gate)  [B*N][D]
-  const __bf16* dout;   // gradient wrt forward output [B*N][D]
-  const float* lse;     // [B][H][N]
+  const __bf16* q;      // [B*NQ][q_rs]; query side / key side split as in AttnFwdArgs
+  const __bf16* k;      // [B*N][kv_rs]
+  const __bf16* v;
+  const __bf16* out;    // forward output (post gate)  [B*NQ][D]
+  const __bf16* dout;   // gradient wrt forward output [B*NQ][D]
+  const float* lse;     // [B][H][NQ]
   const float* head_gate;
-  const __bf16* dqkv_add;  // optional extra gradient added into dqkv (relation loss), same layout
-  __bf16* dqkv;         // [B*N][3D]
-  int B, N, H;
+  const __bf16* dq_add; // optional extra gradients added in (relation loss), laid out like dq / dk / dv
+  const __bf16* dk_add;
+  const __bf16* dv_add;
+  __bf16* dq;           // [B*NQ][dq_rs]
+  __bf16* dk;           // [B*N][dkv_rs]
+  __bf16* dv;
+  int B, N, NQ, H;
+  int q_rs, kv_rs, dq_rs, dkv_rs;
   float scale;
 };
 
@@ -250,28 +263,28 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int D = a.H * HD, N = a.N;
-  const size_t rs = (size_t)3 * D;
-  const __bf16* qbase = a.qkv + (size_t)b * N * rs + h * HD;
+  const int D = a.H * HD, N = a.N, NQ = a.NQ;
+  const size_t rs = (size_t)a.q_rs, krs = (size_t)a.kv_rs;
+  const __bf16* qbase = a.q + (size_t)b * NQ * rs + h * HD;
   const float gate = a.head_gate ? a.head_gate[h] : 1.0f;
-  const __bf16* dobase = a.dout + (size_t)b * N * D + h * HD;
-  const __bf16* obase = a.out + (size_t)b * N * D + h * HD;
+  const __bf16* dobase = a.dout + (size_t)b * NQ * D + h * HD;
+  const __bf16* obase = a.out + (size_t)b * NQ * D + h * HD;
 
   {
     // Q, K, V images by LDS-DMA (issued first: they are in flight while the rest of the prologue runs); dO (scaled by the
     // head gate), the O rows and lse go through registers because delta[q] = sum_d dO[q][d] O[q][d] needs them there
     constexpr int NT = BWD_WAVES * 64;
-    dma_image<BWD_WAVES>(q_img, qbase, rs, N, wave, lane);
-    dma_image<BWD_WAVES>(k_img, qbase + D, rs, N, wave, lane);
-    dma_image<BWD_WAVES>(v_img, qbase + 2 * D, rs, N, wave, lane);
+    dma_image<BWD_WAVES>(q_img, qbase, rs, NQ, wave, lane);
+    dma_image<BWD_WAVES>(k_img, a.k + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
+    dma_image<BWD_WAVES>(v_img, a.v + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
     RowRegs<NT> dr, orr;
     float ls[RowRegs<NT>::ITERS];
-    fetch_rows(dr, dobase, (size_t)D, N, tid);
-    fetch_rows(orr, obase, (size_t)D, N, tid);
+    fetch_rows(dr, dobase, (size_t)D, NQ, tid);
+    fetch_rows(orr, obase, (size_t)D, NQ, tid);
 #pragma unroll
     for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
       const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
-      ls[it] = (row < N && c == 0) ? a.lse[((size_t)b * a.H + h) * N + row] * 1.4426950408889634f : 0.f;
+      ls[it] = (row < NQ && c == 0) ? a.lse[((size_t)b * a.H + h) * NQ + row] * 1.4426950408889634f : 0.f;
     }
     for (int i = tid; i < 2 * DST_BYTES / 16; i += NT) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
       dk[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-  const int nblk = (N + 31) >> 5;
+  const int nblk = (NQ + 31) >> 5;
   for (int qb = 0; qb < nblk; ++qb) {
     char* dst = dst_buf + (qb & 1) * DST_BYTES;
     // ---- S, dP for this wave's key tiles x the block's two query tiles; dV^T, dK^T straight from registers
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = kok && (qb * 32 + i * 16 + g * 4 + r < N);
+            const bool ok = kok && (qb * 32 + i * 16 + g * 4 + r < NQ);
             const float p = ok ? exp2f(sv[r] * c2 - l2[i][r]) : 0.f;
             pp[i][r] = p;
             ds[i][r] = p * (dp[r] - dl[i][r]) * a.scale;
@@ -396,11 +409,11 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
         for (int u = 0; u < 1; ++u) dq[u] = mfma16(img_tr_frag(k_img, ks * 32, (dt0 + u) * 16, lane), bfr, dq[u]);
       }
       const int q = qb * 32 + i * 16 + lc;
-      if (q < N) {
+      if (q < NQ) {
 #pragma unroll
         for (int u = 0; u < 1; ++u) {
-          const size_t o = ((size_t)b * N + q) * rs + h * HD + (dt0 + u) * 16 + g * 4;
-          store_grad4(a.dqkv + o, a.dqkv_add ? a.dqkv_add + o : nullptr, dq[u]);
+          const size_t o = ((size_t)b * NQ + q) * a.dq_rs + h * HD + (dt0 + u) * 16 + g * 4;
+          store_grad4(a.dq + o, a.dq_add ? a.dq_add + o : nullptr, dq[u]);
         }
       }
     }
@@ -427,19 +440,19 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
       for (int half = 0; half < 2; ++half) {
         const int row = half * 8 + (lane >> 3), c8 = lane & 7, key = kt * 16 + row;
         if (key < N) {
-          const size_t o = ((size_t)b * N + key) * rs + h * HD + c8 * 8;
+          const size_t oo = ((size_t)b * N + key) * a.dkv_rs + h * HD + c8 * 8;
 #pragma unroll
-          for (int which = 0; which < 2; ++which) {            // 0: dK (+D), 1: dV (+2D)
+          for (int which = 0; which < 2; ++which) {            // 0: dK, 1: dV
             const char* src = slab + which * 16 * SROW + row * SROW + c8 * 32;
             f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
-            const size_t oo = o + (which + 1) * (size_t)D;
-            if (a.dqkv_add) {
-              const bf16x8 e = *(const bf16x8*)(a.dqkv_add + oo);
+            const __bf16* add = which ? a.dv_add : a.dk_add;
+            if (add) {
+              const bf16x8 e = *(const bf16x8*)(add + oo);
               lo += (f32x4){bf2f(e[0]), bf2f(e[1]), bf2f(e[2]), bf2f(e[3])};
               hi += (f32x4){bf2f(e[4]), bf2f(e[5]), bf2f(e[6]), bf2f(e[7])};
             }
             const bf16x8 v = {f2bf(lo[0]), f2bf(lo[1]), f2bf(lo[2]), f2bf(lo[3]), f2bf(hi[0]), f2bf(hi[1]), f2bf(hi[2]), f2bf(hi[3])};
-            *(bf16x8*)(a.dqkv + oo) = v;
+            *(bf16x8*)((which ? a.dv : a.dk) + oo) = v;
           }
         }
       }
@@ -452,11 +465,9 @@ constexpr int BWD_LDS = 4 * IMG_BYTES + 2 * DST_BYTES + 2 * KROWS * 4;          
 
 }  // namespace
 
-extern "C" int devit_attn_fwd(const void* qkv, void* out, float* lse, const float* head_gate, int B, int N, int H,
-                              int head_dim, float scale, int dtype16, void* stream) {
-  DEVIT_CHECK(qkv && out && (dtype16 == 0 || dtype16 == 1), DEVIT_ERR_ARG, "devit_attn_fwd: bad argument");
-  DEVIT_CHECK(head_dim == HD && N > 0 && N <= MAXT * 16 && B > 0 && H > 0, DEVIT_ERR_SHAPE,
-              "devit_attn_fwd: needs head_dim == 64 and N <= 208 (got hd=%d N=%d)", head_dim, N);
+namespace {
+
+int launch_attn_fwd(const AttnFwdArgs& a, int dtype16, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
@@ -465,13 +476,53 @@ extern "C" int devit_attn_fwd(const void* qkv, void* out, float* lse, const floa
     DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "devit_attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  AttnFwdArgs a{(const __bf16*)qkv, (__bf16*)out, lse, head_gate, B, N, H, scale};
   if (dtype16)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(FWD_WAVES * 64), FWD_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(a.B * a.H), dim3(FWD_WAVES * 64), FWD_LDS, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(FWD_WAVES * 64), FWD_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(a.B * a.H), dim3(FWD_WAVES * 64), FWD_LDS, (hipStream_t)stream, a);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
+}
+
+int launch_attn_bwd(const AttnBwdArgs& a, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "devit_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(BWD_WAVES * 64), BWD_LDS, (hipStream_t)stream, a);
+  DEVIT_LAUNCH_CHECK();
+  return DEVIT_OK;
+}
+
+bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int devit_attn_fwd(const void* qkv, void* out, float* lse, const float* head_gate, int B, int N, int H,
+                              int head_dim, float scale, int dtype16, void* stream) {
+  DEVIT_CHECK(qkv && out && (dtype16 == 0 || dtype16 == 1), DEVIT_ERR_ARG, "devit_attn_fwd: bad argument");
+  DEVIT_CHECK(head_dim == HD && N > 0 && N <= MAXT * 16 && B > 0 && H > 0, DEVIT_ERR_SHAPE,
+              "devit_attn_fwd: needs head_dim == 64 and N <= 208 (got hd=%d N=%d)", head_dim, N);
+  const int D = H * HD;
+  const __bf16* p = (const __bf16*)qkv;
+  AttnFwdArgs a{p, p + D, p + 2 * D, (__bf16*)out, lse, head_gate, B, N, N, H, 3 * D, 3 * D, scale};
+  return launch_attn_fwd(a, dtype16, stream);
+}
+
+extern "C" int devit_attn_fwd_rows(const void* q, int q_ld, const void* kv, int kv_ld, void* out, float* lse,
+                                   const float* head_gate, int B, int NQ, int N, int H, int head_dim, float scale,
+                                   int dtype16, void* stream) {
+  DEVIT_CHECK(q && kv && out && (dtype16 == 0 || dtype16 == 1), DEVIT_ERR_ARG, "devit_attn_fwd_rows: bad argument");
+  DEVIT_CHECK(head_dim == HD && N > 0 && N <= MAXT * 16 && NQ > 0 && NQ <= N && B > 0 && H > 0, DEVIT_ERR_SHAPE,
+              "devit_attn_fwd_rows: needs head_dim == 64, NQ <= N <= 208 (got hd=%d NQ=%d N=%d)", head_dim, NQ, N);
+  const int D = H * HD;
+  DEVIT_CHECK(q_ld >= D && kv_ld >= 2 * D && q_ld % 8 == 0 && kv_ld % 8 == 0 && al16(q) && al16(kv) && al16(out),
+              DEVIT_ERR_ARG, "devit_attn_fwd_rows: q_ld=%d kv_ld=%d / pointers must be 16-byte aligned and hold H*64 (2*H*64) features", q_ld, kv_ld);
+  const __bf16* p = (const __bf16*)kv;
+  AttnFwdArgs a{(const __bf16*)q, p, p + D, (__bf16*)out, lse, head_gate, B, N, NQ, H, q_ld, kv_ld, scale};
+  return launch_attn_fwd(a, dtype16, stream);
 }
 
 extern "C" int devit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
@@ -480,15 +531,29 @@ extern "C" int devit_attn_bwd(const void* qkv, const void* out, const void* dout
   DEVIT_CHECK(qkv && out && dout && lse && dqkv, DEVIT_ERR_ARG, "devit_attn_bwd: null pointer");
   DEVIT_CHECK(head_dim == HD && N > 0 && N <= MAXT * 16 && B > 0 && H > 0, DEVIT_ERR_SHAPE,
               "devit_attn_bwd: needs head_dim == 64 and N <= 208 (got hd=%d N=%d)", head_dim, N);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "devit_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  AttnBwdArgs a{(const __bf16*)qkv, (const __bf16*)out, (const __bf16*)dout, lse, head_gate,
-                (const __bf16*)dqkv_add, (__bf16*)dqkv, B, N, H, scale};
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(BWD_WAVES * 64), BWD_LDS, (hipStream_t)stream, a);
-  DEVIT_LAUNCH_CHECK();
-  return DEVIT_OK;
+  const int D = H * HD;
+  const __bf16* p = (const __bf16*)qkv;
+  const __bf16* ad = (const __bf16*)dqkv_add;
+  __bf16* d = (__bf16*)dqkv;
+  AttnBwdArgs a{p, p + D, p + 2 * D, (const __bf16*)out, (const __bf16*)dout, lse, head_gate,
+                ad, ad ? ad + D : nullptr, ad ? ad + 2 * D : nullptr, d, d + D, d + 2 * D,
+                B, N, N, H, 3 * D, 3 * D, 3 * D, 3 * D, scale};
+  return launch_attn_bwd(a, stream);
+}
+
+extern "C" int devit_attn_bwd_rows(const void* q, int q_ld, const void* kv, int kv_ld, const void* out, const void* dout,
+                                   const float* lse, const float* head_gate, void* dq, int dq_ld, void* dkv, int dkv_ld,
+                                   int B, int NQ, int N, int H, int head_dim, float scale, void* stream) {
+  DEVIT_CHECK(q && kv && out && dout && lse && dq && dkv, DEVIT_ERR_ARG, "devit_attn_bwd_rows: null pointer");
+  DEVIT_CHECK(head_dim == HD && N > 0 && N <= MAXT * 16 && NQ > 0 && NQ <= N && B > 0 && H > 0, DEVIT_ERR_SHAPE,
+              "devit_attn_bwd_rows: needs head_dim == 64, NQ <= N <= 208 (got hd=%d NQ=%d N=%d)", head_dim, NQ, N);
+  const int D = H * HD;
+  DEVIT_CHECK(q_ld >= D && dq_ld >= D && kv_ld >= 2 * D && dkv_ld >= 2 * D && q_ld % 8 == 0 && kv_ld % 8 == 0 &&
+                  dq_ld % 8 == 0 && dkv_ld % 8 == 0 && al16(q) && al16(kv) && al16(out) && al16(dout) && al16(dq) && al16(dkv),
+              DEVIT_ERR_ARG, "devit_attn_bwd_rows: leading dimensions / pointers must be 16-byte aligned and wide enough");
+  const __bf16* p = (const __bf16*)kv;
+  __bf16* d = (__bf16*)dkv;
+  AttnBwdArgs a{(const __bf16*)q, p, p + D, (const __bf16*)out, (const __bf16*)dout, lse, head_gate,
+                nullptr, nullptr, nullptr, (__bf16*)dq, d, d + D, B, N, NQ, H, q_ld, kv_ld, dq_ld, dkv_ld, scale};
+  return launch_attn_bwd(a, stream);
 }

@@ -971,6 +971,9 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   // filled from row N-1 and the waves that own them skip the epilogue (variant 0, bf16 / f32 store only)
   const bool ragged_ok = variant == 0 && light_epi && N % 256 == 128 && N >= 1024;
   if (M % 256 == 0 && (N % 256 == 0 || ragged_ok) && (K >= 1536 || (K >= DEVIT_RAGGED_MIN_K && light_epi) || gelu_epi) && variant != 3) cfg = 3;
+  // too few 256x256 tiles to give every CU one (the token-row GEMMs of the lean last block, M = 512): 128x128 tiles
+  // quarter the time of the longest workgroup; same accumulation order per output element either way
+  if (cfg == 3 && (long long)(M / 256) * ((N + 255) / 256) * batch < 64) cfg = 1;
   static const int exact = getenv("DEVIT_GEMM_FORCE") ? atoi(getenv("DEVIT_GEMM_FORCE")) : 0;   // tools/gpu_tiles.sh
   if (exact == 1 || (exact == 3 && M % 256 == 0 && (N % 256 == 0 || ragged_ok) && variant != 3)) cfg = exact;
   const int bm = cfg == 1 ? 128 : 256, bn = bm;

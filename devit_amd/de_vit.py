@@ -10,7 +10,9 @@ raises (no fallback); the CPU restatement used for parity lives in oracle/.
 The nn.Linear / nn.LayerNorm / nn.Conv2d children are parameter containers (so initialisation and
 checkpoint keys equal the reference's); their own forward() is never called.
 """
+import contextlib
 import math
+import os
 from functools import partial
 
 import torch
@@ -220,9 +222,31 @@ def draw_dp_scales(blocks_params, B, device, training):
     return [(sc[i, 0], sc[i, 1]) if p > 0. else None for i, p in enumerate(probs)]
 
 
+LEAN_TAIL = os.environ.get("DEVIT_LEAN_TAIL", "1") == "1"      # 0: lean_tail() is a no-op (A/B runs)
+
+
+@contextlib.contextmanager
+def lean_tail(*models):
+    """Forwards of `models` inside this context promise that the caller reads nothing of the LAST block but the class /
+    distillation tokens of its output (through 'output' / 'last_tokens'): not its q/k/v (the 'qkv' entry of the last block
+    is None; DEKD reads the middle block's, engine.py:91-92), not `head_output` / `neuron_output` of its modules.  The
+    model then runs that block on the token rows only (ops._tail_forward): the reference computes all 198 rows and
+    keeps two (models/de_vit.py:286-288).  Logits are bit-identical.  engine.distill_forward / evaluate enter it."""
+    vits = [m.module if hasattr(m, "module") else m for m in models]
+    prev = [getattr(v, "_lean_tail", False) for v in vits]
+    for v in vits:
+        v._lean_tail = LEAN_TAIL
+    try:
+        yield
+    finally:
+        for v, p in zip(vits, prev):
+            v._lean_tail = p
+
+
 def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=None, dp_scales="draw", exact_gelu=0,
-               precision="bf16", qkv_pad_layers=None):
-    """Run a list of Blocks as one EncoderFn node.  Returns (x, qkv tuples, att tensors, enc tensors)."""
+               precision="bf16", qkv_pad_layers=None, lean_tokens=0):
+    """Run a list of Blocks as one EncoderFn node.  Returns (x, qkv tuples, att tensors, enc tensors).
+    lean_tokens > 0 (see lean_tail): x comes back as [B, lean_tokens, D] and the last block's qkv entry is None."""
     L.require_device(x)
     if x.dtype != torch.float32:
         x = x.float()
@@ -233,8 +257,12 @@ def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=Non
     bps = [b.block_params(x.device, precision == "f16") for b in blocks]
     if dp_scales == "draw":
         dp_scales = draw_dp_scales(bps, B, x.device, training)
+    nb = len(blocks)
+    lean = lean_tokens if (lean_tokens and nb >= 2 and precision != "f32" and not want_att and not want_enc and
+                           not bps[-1].compacted and
+                           (not want_qkv or (qkv_pad_layers is not None and nb - 1 not in qkv_pad_layers))) else 0
     cfg = ops.EncoderCfg(bps, training, dp_scales, want_qkv, want_att, want_enc, exact_gelu=exact_gelu,
-                         grad_ready=grad_ready, qkv_pad_layers=qkv_pad_layers)
+                         grad_ready=grad_ready, qkv_pad_layers=qkv_pad_layers, lean_tokens=lean)
     cfg.grad_enabled = torch.is_grad_enabled()
     flat = [p for bp in bps for p in bp.all_params()]
     if precision == "f32":
@@ -244,12 +272,12 @@ def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=Non
         outs = ops_f32.EncoderF32Fn.apply(x, cfg, *flat)
     else:
         outs = ops.EncoderFn.apply(x, cfg, *flat)
-    nb = len(blocks)
     i = 1
     qkvs = atts = encs = None
     if want_qkv:
-        qkvs = [qkv_views(t, B, N, bps[j].num_heads) for j, t in enumerate(outs[i:i + nb])]
-        i += nb
+        nq = nb - 1 if lean else nb
+        qkvs = [qkv_views(t, B, N, bps[j].num_heads) for j, t in enumerate(outs[i:i + nq])] + [None] * (nb - nq)
+        i += nq
     if want_att:
         atts = [t.view(B, N, D) for t in outs[i:i + nb]]
         i += nb
@@ -403,7 +431,8 @@ class VisionTransformer(nn.Module):
         xo, qkvs, atts, encs = run_blocks(list(self.blocks), x, self.training, output_qkv, output_att, output_encoders,
                                           grad_ready=self.grad_ready, exact_gelu=self.exact_gelu,
                                           precision=self.precision,
-                                          qkv_pad_layers=getattr(self, "qkv_pad_layers", None))
+                                          qkv_pad_layers=getattr(self, "qkv_pad_layers", None),
+                                          lean_tokens=self.num_tokens if getattr(self, "_lean_tail", False) else 0)
         depth = len(self.blocks)
         encoder_outputs = [emb] if output_emb else []
         encoder_outputs += encs if output_encoders else [None] * depth

@@ -34,7 +34,7 @@ def _side_forward(teacher_model, samples, main, side):
     side.wait_stream(main)
     prev, ops.ARENA_ALLOC_STREAM = ops.ARENA_ALLOC_STREAM, main
     try:
-        with torch.cuda.stream(side), torch.no_grad():
+        with torch.cuda.stream(side), torch.no_grad(), de_vit.lean_tail(teacher_model):
             return teacher_model(samples, output_qkv=True)
     finally:
         ops.ARENA_ALLOC_STREAM = prev
@@ -53,10 +53,12 @@ def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3)
     pre_teacher = None
     if teacher_outputs is None and os.environ.get("DEVIT_TEACHER_STREAM", "1") == "1" and samples.is_cuda:
         pre_teacher = _teacher_forward_async(teacher_model, samples)
-    if dp_scales != "draw":   # explicit DropPath masks (parity tests)
-        outputs = _forward_with_dp(vit, samples, dp_scales)
-    else:
-        outputs = model(samples, output_qkv=True)                                   # engine.py:70
+    # only the logits and the middle block's q/k/v are read below: the last block runs on its two token rows (de_vit.lean_tail)
+    with de_vit.lean_tail(vit):
+        if dp_scales != "draw":   # explicit DropPath masks (parity tests)
+            outputs = _forward_with_dp(vit, samples, dp_scales)
+        else:
+            outputs = model(samples, output_qkv=True)                               # engine.py:70
     logits, qkvs = outputs['output'], outputs['qkv']
     if teacher_outputs is None:                                                     # engine.py:73-76
         teacher_outputs = pre_teacher() if pre_teacher is not None else _teacher_forward(teacher_model, samples)
@@ -98,7 +100,7 @@ def _teacher_forward(teacher_model, samples):
     """Frozen teacher forward.  With DEVIT_TEACHER_STREAM=1 it is enqueued on a side stream before the student
     forward has drained, so the tail rounds of one model's GEMMs are filled by the other's workgroups."""
     if os.environ.get("DEVIT_TEACHER_STREAM", "1") != "1" or not samples.is_cuda:
-        with torch.no_grad():
+        with torch.no_grad(), de_vit.lean_tail(teacher_model):
             return teacher_model(samples, output_qkv=True)
     main = torch.cuda.current_stream()
     side = _side_stream.setdefault(samples.device.index, torch.cuda.Stream())
@@ -211,7 +213,8 @@ def _forward_with_dp(vit, samples, dp_scales):
     x = vit.embed(samples)
     xo, qkvs, _, _ = de_vit.run_blocks(list(vit.blocks), x, vit.training, True, False, False,
                                        grad_ready=vit.grad_ready, dp_scales=dp_scales, precision=vit.precision,
-                                       qkv_pad_layers=getattr(vit, "qkv_pad_layers", None))
+                                       qkv_pad_layers=getattr(vit, "qkv_pad_layers", None),
+                                       lean_tokens=vit.num_tokens if getattr(vit, "_lean_tail", False) else 0)
     heads = vit._tokens_and_logits(xo, True)
     return {'output': (heads[1], heads[2]) if vit.training else (heads[1] + heads[2]) / 2, 'qkv': qkvs}
 
@@ -294,7 +297,8 @@ def evaluate(data_loader, model, device):
     for images, target in metric_logger.log_every(data_loader, 10, 'Test:'):
         images = images.to(device, non_blocking=True)
         target = target.to(device, non_blocking=True)
-        output = model(images)
+        with de_vit.lean_tail(model):                                   # only the logits are read (engine.py:31-32)
+            output = model(images)
         loss = losses.DistillLoss(losses.SoftTargetCrossEntropy(), 'none', 0., 1.)(output, None, target)
         acc1, acc5 = accuracy(output, target, topk=(1, min(5, output.shape[1])))
         metric_logger.update(loss=loss.item())

@@ -218,12 +218,16 @@ class EncoderCfg:
     """Non-tensor arguments of EncoderFn."""
 
     def __init__(self, blocks, training, dp_scales, want_qkv, want_att, want_enc, eps=1e-6, exact_gelu=0,
-                 grad_ready=None, qkv_pad_layers=None):
+                 grad_ready=None, qkv_pad_layers=None, lean_tokens=0):
         self.blocks, self.training, self.dp_scales = blocks, training, dp_scales
         self.want_qkv, self.want_att, self.want_enc = want_qkv, want_att, want_enc
         self.eps, self.exact_gelu, self.grad_ready = eps, exact_gelu, grad_ready
         # blocks whose packed qkv output gets the zeroed overhang rows RelationLossFn reads (None: every block)
         self.qkv_pad_layers = qkv_pad_layers
+        # > 0: the caller reads only the first `lean_tokens` rows of every image of the encoder output (the class /
+        # distillation tokens, models/de_vit.py:286-288) and nothing of the last block besides: that block then runs as
+        # _tail_forward / _tail_backward and the output is [B, lean_tokens, D]
+        self.lean_tokens = lean_tokens
 
 
 def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
@@ -335,6 +339,117 @@ def scale_cast(dx, rowscale, N):
 
 
 # ----------------------------------------------------------------------------------------------
+# The LAST block when only the class / distillation tokens of its output are read (models/de_vit.py:286-288 takes
+# x[:, 0], x[:, 1] after the final norm, and engine.py:91-92 takes q/k/v of the middle block only): of the last block
+# only K and V are needed on all rows; the Q projection, attention, proj, LN2, fc1 and fc2 run on the B * ntok token
+# rows.  Same kernels and per-row arithmetic as _block_forward, so the token rows -- and the logits -- are bit-identical
+# to the full block's; the reference computes (and then drops) the other 196 rows per image.
+# ----------------------------------------------------------------------------------------------
+def _gather_tok(src2d, B, N, ntok, cols, dtype, dev, pad=True):
+    """Rows (b, t < ntok) of a [B*N (+pad), cols] matrix as a dense [pad_rows(B*ntok), cols] matrix (zero pad rows)."""
+    T = B * ntok
+    out = rows_alloc(T, cols, dtype, dev) if pad else torch.empty((T, cols), dtype=dtype, device=dev)
+    out[:T].view(B, ntok, cols).copy_(src2d[:B * N].view(B, N, cols)[:, :ntok])
+    return out
+
+
+def _tail_forward(x, bp, dp, cfg, need_grad, ntok):
+    """x: fp32 [B, N, D] contiguous (output of the block before the last).  Returns (x2_tok fp32 [B, ntok, D], saved)."""
+    B, N, D = x.shape
+    M, T, H, dev = B * N, B * ntok, bp.num_heads, x.device
+    t16 = 1 if bp.qkv_w16.dtype == F16 else 0
+    dt = F16 if t16 else BF16
+    if t16 and need_grad:
+        raise L.DevitError('precision="f16" is forward-only (frozen teacher): run it under torch.no_grad()')
+    x2 = x.view(M, D)
+    ln1 = rows_alloc(M, D, dt, dev)
+    mean1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
+    rstd1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
+    layernorm_fwd(x2, M, D, bp.n1w, bp.n1b, cfg.eps, y_bf16=ln1, mean=mean1, rstd=rstd1, dtype16=t16)
+    kv = rows_alloc(M, 2 * D, dt, dev)                                   # (K | V) of every row
+    linear_fwd(ln1, bp.qkv_w16[D:], bp.qkv_b[D:], M, out=kv, dtype16=t16)
+    ln1_tok = _gather_tok(ln1, B, N, ntok, D, dt, dev)
+    q_tok = rows_alloc(T, D, dt, dev)                                    # Q of the token rows
+    linear_fwd(ln1_tok, bp.qkv_w16[:D], bp.qkv_b[:D], T, out=q_tok, dtype16=t16)
+    attn_o = rows_alloc(T, D, dt, dev)
+    lse = torch.empty((B, H, ntok), dtype=F32, device=dev) if need_grad else None
+    _bracketed("attention_fwd_rows", (M * 2 * D + 2 * T * D) * 2, lambda: call(
+        "devit_attn_fwd_rows", ptr(q_tok), D, ptr(kv), 2 * D, ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, ntok, N, H,
+        D // H, (D // H) ** -0.5, t16, stream_ptr()))
+    x_tok = _gather_tok(x2, B, N, ntok, D, F32, dev, pad=False)
+    dp1, dp2 = dp if dp is not None else (None, None)
+    x1 = torch.empty((B, ntok, D), dtype=F32, device=dev)
+    linear_fwd(attn_o, bp.proj_w16, bp.proj_b, T, out=x1.view(T, D), kind=L.EPI_RESIDUAL_F32, res=x_tok, rowscale=dp1,
+               rows_per_scale=ntok, dtype16=t16)
+    ln2 = rows_alloc(T, D, dt, dev)
+    mean2 = torch.empty(T, dtype=F32, device=dev) if need_grad else None
+    rstd2 = torch.empty(T, dtype=F32, device=dev) if need_grad else None
+    layernorm_fwd(x1.view(T, D), T, D, bp.n2w, bp.n2b, cfg.eps, y_bf16=ln2, mean=mean2, rstd=rstd2, dtype16=t16)
+    Hd = bp.fc1_w16.shape[0]
+    h = rows_alloc(T, Hd, dt, dev)
+    h_pre = rows_alloc(T, Hd, dt, dev) if need_grad else None
+    linear_fwd(ln2, bp.fc1_w16, bp.fc1_b, T, out=h, kind=L.EPI_GELU_BF16, colscale=bp.neuron_gate, aux=h_pre,
+               exact_gelu=cfg.exact_gelu, dtype16=t16)
+    x2o = torch.empty((B, ntok, D), dtype=F32, device=dev)
+    linear_fwd(h, bp.fc2_w16, bp.fc2_b, T, out=x2o.view(T, D), kind=L.EPI_RESIDUAL_F32, res=x1.view(T, D), rowscale=dp2,
+               rows_per_scale=ntok, dtype16=t16)
+    s = None
+    if need_grad:
+        s = dict(x=x, ln1=ln1, mean1=mean1, rstd1=rstd1, kv=kv, ln1_tok=ln1_tok, q_tok=q_tok, attn_o=attn_o, lse=lse,
+                 x1=x1, ln2=ln2, mean2=mean2, rstd2=rstd2, h=h, h_pre=h_pre, dp1=dp1, dp2=dp2, ntok=ntok)
+    return x2o, s
+
+
+def _tail_backward(dx, s, bp, cfg):
+    """dx: fp32 [B, ntok, D] gradient of _tail_forward's output.  Returns the fp32 [B, N, D] gradient of its input.
+    Every product that the full block's backward forms from the 196 untouched rows per image is an exact zero there (their
+    output gradient is zero), so the sums here hold the same terms; the token rows of dln1 are produced by one K = 3D GEMM
+    like the full path's (one rounding), the other rows by the K = 2D GEMM over (dK | dV) -- the same sum without its zeros."""
+    ntok = s["ntok"]
+    x = s["x"]
+    B, N, D = x.shape
+    M, T, H, dev = B * N, B * ntok, bp.num_heads, x.device
+    Hd = bp.fc1_w.shape[0]
+    dx = dx.contiguous()
+    g2 = scale_cast(dx, s["dp2"], ntok)
+    # ---- MLP branch on the token rows
+    linear_wgrad(g2, s["h"], grad_buf(bp.fc2_w), grad_buf(bp.fc2_b), T)
+    dh_pre = rows_alloc(T, Hd, BF16, dev)
+    linear_dgrad(g2, bp.fc2_w16, T, out=dh_pre, kind=L.EPI_DGELU_BF16, colscale=bp.neuron_gate, aux_in=s["h_pre"],
+                 exact_gelu=cfg.exact_gelu)
+    dln2 = rows_alloc(T, D, BF16, dev)
+    linear_dgrad(dh_pre, bp.fc1_w16, T, out=dln2)
+    linear_wgrad(dh_pre, s["ln2"], grad_buf(bp.fc1_w), grad_buf(bp.fc1_b), T)
+    dx1 = torch.empty((B, ntok, D), dtype=F32, device=dev)
+    g1 = rows_alloc(T, D, BF16, dev)
+    layernorm_bwd(dln2, False, s["x1"].view(T, D), T, D, s["mean2"], s["rstd2"], bp.n2w, dx.view(T, D), dx1.view(T, D),
+                  g1, s["dp1"], ntok, grad_buf(bp.n2w), grad_buf(bp.n2b), gsum=grad_buf(bp.proj_b))
+    # ---- attention branch: dO on the token rows; dQ there, dK / dV on every row
+    dattn = rows_alloc(T, D, BF16, dev)
+    linear_dgrad(g1, bp.proj_w16, T, out=dattn)
+    linear_wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), None, T)
+    dqkv_tok = rows_alloc(T, 3 * D, BF16, dev)                           # (dQ | dK | dV) of the token rows
+    dkv = rows_alloc(M, 2 * D, BF16, dev)
+    _bracketed("attention_bwd_rows", (M * 4 * D + 4 * T * D) * 2, lambda: call(
+        "devit_attn_bwd_rows", ptr(s["q_tok"]), D, ptr(s["kv"]), 2 * D, ptr(s["attn_o"]), ptr(dattn), ptr(s["lse"]),
+        ptr(bp.head_gate), ptr(dqkv_tok), 3 * D, ptr(dkv), 2 * D, B, ntok, N, H, D // H, (D // H) ** -0.5, stream_ptr()))
+    dqkv_tok[:T].view(B, ntok, 3 * D)[:, :, D:].copy_(dkv[:M].view(B, N, 2 * D)[:, :ntok])
+    dln1 = rows_alloc(M, D, BF16, dev)
+    linear_dgrad(dkv, bp.qkv_w16[D:], M, out=dln1)
+    dln1_tok = rows_alloc(T, D, BF16, dev)
+    linear_dgrad(dqkv_tok, bp.qkv_w16, T, out=dln1_tok)
+    dln1[:M].view(B, N, D)[:, :ntok].copy_(dln1_tok[:T].view(B, ntok, D))
+    gw, gb = grad_buf(bp.qkv_w), grad_buf(bp.qkv_b)
+    linear_wgrad(dkv, s["ln1"], gw[D:], gb[D:], M)
+    linear_wgrad(dqkv_tok[:, :D], s["ln1_tok"], gw[:D], gb[:D], T)
+    dx0 = torch.empty((B, N, D), dtype=F32, device=dev)
+    layernorm_bwd(dln1, False, x.view(M, D), M, D, s["mean1"], s["rstd1"], bp.n1w, None, dx0.view(M, D), None, None, 0,
+                  grad_buf(bp.n1w), grad_buf(bp.n1b))
+    dx0[:, :ntok] += dx1                                                   # the residual path exists on the token rows only
+    return dx0
+
+
+# ----------------------------------------------------------------------------------------------
 # composite path: whole blocks per ctypes call (devit_encoder_fwd / devit_block_bwd, csrc/encoder.hip).
 # Same kernels, arguments and order as _block_forward / _block_backward above (which stay as the granular path that
 # bench.py's per-kernel instrumentation and the rare extra-gradient cases use); one arena per encoder call instead of
@@ -402,22 +517,23 @@ def _weights_struct(bp):
 
 class _EncoderRun:
     """What one composite forward leaves behind for backward: the ctypes argument arrays and the arena they point into."""
-    __slots__ = ("weights", "acts", "arena", "x", "dims", "views", "dps")
+    __slots__ = ("weights", "acts", "arena", "x", "dims", "views", "dps", "nb")
 
 
-def _encoder_forward_composite(x, cfg, need_grad):
+def _encoder_forward_composite(x, cfg, need_grad, nb):
+    """Blocks [0, nb) of cfg.blocks."""
     B, N, D = x.shape
-    M, dev, nb = B * N, x.device, len(cfg.blocks)
+    M, dev = B * N, x.device
     mp = pad_rows(M)
     weights = (L.BlockWeights * nb)()
     acts = (L.BlockActs * nb)()
     run = _EncoderRun()
     # one allocation per block (uniform sizes: the caching allocator hands the same blocks back every step; a single
     # 8-13 GB arena per encoder call gets split by other requests and re-hipMalloc'ed -- measured 150 ms of host per step)
-    run.weights, run.acts, run.arena, run.x, run.dims, run.dps = weights, acts, [], x, (B, N, D), cfg.dp_scales
+    run.weights, run.acts, run.arena, run.x, run.dims, run.dps, run.nb = weights, acts, [], x, (B, N, D), cfg.dp_scales, nb
     views = []
     x_ptr = x.data_ptr()
-    for i, bp in enumerate(cfg.blocks):
+    for i, bp in enumerate(cfg.blocks[:nb]):
         weights[i] = _weights_struct(bp)
         pad = bool(cfg.want_qkv) and (cfg.qkv_pad_layers is None or i in cfg.qkv_pad_layers)
         flags = (L.BLK_SAVE if need_grad else 0) | (L.BLK_QKV_PAD if pad else 0) | (L.BLK_ATT if cfg.want_att else 0)
@@ -463,7 +579,7 @@ def _wgrads_struct(bp):
 def _encoder_backward_composite(run, cfg, dx, dqkvs):
     """dx: fp32 [B,N,D] contiguous gradient of the encoder output.  Returns the gradient of the encoder input."""
     B, N, D = run.dims
-    M, dev, nb = B * N, dx.device, len(cfg.blocks)
+    M, dev, nb = B * N, dx.device, run.nb
     mp = pad_rows(M)
     Hd = run.weights[0].hidden
     sz, offs, tot = _bwd_sizes(B, N, D, Hd)
@@ -520,9 +636,15 @@ class EncoderFn(torch.autograd.Function):
             raise L.DevitError("a compacted model (devit_amd.shrink.compact) is inference-only: run it under "
                                "torch.no_grad() or call shrink.uncompact(model) before training")
         ctx.run = None
+        nb = len(cfg.blocks)
+        # lean tail (EncoderCfg.lean_tokens): the last block runs on the token rows only
+        lean = cfg.lean_tokens if (cfg.lean_tokens and nb >= 2 and not cfg.want_att and not cfg.want_enc and
+                                   not getattr(cfg.blocks[-1], "compacted", False)) else 0
+        nbody = nb - 1 if lean else nb
+        dp_last = cfg.dp_scales[nb - 1] if cfg.dp_scales is not None else None
+        ctx.tail = None
         if COMPOSITE and PROFILE is None and PROFILE_HBM is None:
-            run = _encoder_forward_composite(x, cfg, need_grad)
-            nb = len(cfg.blocks)
+            run = _encoder_forward_composite(x, cfg, need_grad, nbody)
             qkvs = [v["qkv"] for v in run.views] if cfg.want_qkv else []
             atts = [v["att"] for v in run.views] if cfg.want_att else []
             encs = [run.views[i]["x2"].clone() if i == nb - 1 else run.views[i]["x2"] for i in range(nb)] if cfg.want_enc else []
@@ -530,9 +652,12 @@ class EncoderFn(torch.autograd.Function):
             ctx.run = run if need_grad else None
             ctx.counts = (len(qkvs), len(atts), len(encs))
             ctx.set_materialize_grads(False)
-            return (run.views[-1]["x2"],) + tuple(qkvs) + tuple(atts) + tuple(encs)
+            xo = run.views[-1]["x2"]
+            if lean:
+                xo, ctx.tail = _tail_forward(xo, cfg.blocks[-1], dp_last, cfg, need_grad, lean)
+            return (xo,) + tuple(qkvs) + tuple(atts) + tuple(encs)
         saved, qkvs, atts, encs = [], [], [], []
-        for i, bp in enumerate(cfg.blocks):
+        for i, bp in enumerate(cfg.blocks[:nbody]):
             dp = cfg.dp_scales[i] if cfg.dp_scales is not None else None
             pad = bool(cfg.want_qkv) and (cfg.qkv_pad_layers is None or i in cfg.qkv_pad_layers)
             x, qkv, att, s = _block_forward(x, bp, dp, cfg, need_grad, cfg.want_att, pad)
@@ -543,6 +668,8 @@ class EncoderFn(torch.autograd.Function):
                 atts.append(att)
             if cfg.want_enc:
                 encs.append(x.clone() if i == len(cfg.blocks) - 1 else x)
+        if lean:
+            x, ctx.tail = _tail_forward(x, cfg.blocks[-1], dp_last, cfg, need_grad, lean)
         ctx.cfg, ctx.saved, ctx.need_grad = cfg, saved, need_grad
         ctx.counts = (len(qkvs), len(atts), len(encs))
         # outputs nobody differentiates (11 of the 12 qkv tensors in the DEKD step) arrive as None in backward, not as
@@ -558,6 +685,16 @@ class EncoderFn(torch.autograd.Function):
         nq, na, ne = ctx.counts
         dqkvs, datts, dencs = dothers[:nq], dothers[nq:nq + na], dothers[nq + na:]
         nb = len(cfg.blocks)
+        nparams = 12 * nb
+        if ctx.tail is not None:          # lean tail: dx is the [B, ntok, D] gradient of the token rows
+            tail, ctx.tail = ctx.tail, None
+            last = cfg.blocks[-1]
+            if dx is None:
+                dx = torch.zeros_like(tail["x1"])
+            dx = _tail_backward(dx, tail, last, cfg)
+            if cfg.grad_ready is not None:
+                cfg.grad_ready(last.all_params())
+            nb -= 1
         if ctx.run is not None:
             run = ctx.run
             if any(d is not None for d in datts) or any(d is not None for d in dencs):
@@ -568,7 +705,7 @@ class EncoderFn(torch.autograd.Function):
                 dx = torch.zeros((B, N, D), dtype=F32, device=run.x.device)
             dx_in = _encoder_backward_composite(run, cfg, dx.contiguous(), dqkvs if nq else None)
             ctx.run = None
-            return (dx_in, None) + (None,) * (12 * nb)
+            return (dx_in, None) + (None,) * nparams
         B, N, D = saved[0]["x"].shape
         if dx is None:
             dx = torch.zeros((B, N, D), dtype=F32, device=saved[0]["x"].device)
@@ -595,7 +732,7 @@ class EncoderFn(torch.autograd.Function):
             saved[i] = None
             if cfg.grad_ready is not None:
                 cfg.grad_ready(bp.all_params())
-        return (dx, None) + (None,) * (12 * nb)
+        return (dx, None) + (None,) * nparams
 
 
 # ----------------------------------------------------------------------------------------------

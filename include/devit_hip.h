@@ -140,6 +140,19 @@ int devit_attn_fwd(const void* qkv, void* out, float* lse, const float* head_gat
                    float scale, int dtype16 /* type of qkv and out: 0 bf16, 1 f16 */, void* stream);
 int devit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* head_gate,
                    const void* dqkv_add, void* dqkv, int B, int N, int H, int head_dim, float scale, void* stream);
+/* The same kernels with the query side apart from the key side: NQ <= N query rows per image against all N keys.
+ * Used for the LAST block when the caller consumes only the class / distillation tokens (models/de_vit.py:286-288 reads
+ * x[:, 0], x[:, 1] after the final norm; engine.py:91-92 reads q/k/v of the middle block only): the other 196 query
+ * rows of that block are never read, so their attention (and projection, MLP) is not computed -- same arithmetic per
+ * computed row, bit-identical outputs.
+ *   q   : bf16 [B*NQ][q_ld], feature h*hd + e        kv  : bf16 [B*N][kv_ld], K at feature h*hd + e, V at H*hd + h*hd + e
+ *   out / dout : bf16 [B*NQ][H*hd]                    lse : f32 [B][H][NQ]
+ *   dq  : bf16 [B*NQ][dq_ld]                          dkv : bf16 [B*N][dkv_ld] (dK | dV), every key row written */
+int devit_attn_fwd_rows(const void* q, int q_ld, const void* kv, int kv_ld, void* out, float* lse, const float* head_gate,
+                        int B, int NQ, int N, int H, int head_dim, float scale, int dtype16, void* stream);
+int devit_attn_bwd_rows(const void* q, int q_ld, const void* kv, int kv_ld, const void* out, const void* dout,
+                        const float* lse, const float* head_gate, void* dq, int dq_ld, void* dkv, int dkv_ld, int B, int NQ,
+                        int N, int H, int head_dim, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole encoder blocks per call.  Replaces Block.forward (models/de_vit.py:103-121: norm1 -> Attention :65-87 ->

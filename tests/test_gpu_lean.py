@@ -1,0 +1,201 @@
+"""The last block on its token rows only (devit_amd.de_vit.lean_tail, ops._tail_forward / _tail_backward, the
+devit_attn_*_rows entry points) against the full block: the reference computes all 198 rows of the last block and reads
+two of them (models/de_vit.py:286-288; q/k/v of the middle block only, engine.py:91-92).
+
+Bars.  Forward: every computed row goes through the same kernels with the same per-row arithmetic, so logits (and at
+bs 8, where the loss kernels reduce in one workgroup, the losses) must be BIT-identical (torch.equal).  Backward: the rows-form attention backward is the packed kernel with one query
+block, bit-identical on identical inputs (asserted below); the weight gradients of the last block reduce over 512 token
+rows instead of 50688 rows of which 50176 contribute exact zeros, i.e. the same terms in another split-K / atomic order:
+fp32 summation-order noise, bar 2e-5 of each gradient's largest element."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import devit_oracle as O
+from oracle.detgen import det_array
+from conftest import chk
+
+pytestmark = pytest.mark.gpu
+C = 25
+GS, GT = O.GEOMETRY["dedeit"], O.GEOMETRY["deit_base_distilled_patch16_224"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def relmax(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,H,N,NQ,gate", [(4, 6, 198, 2, False), (3, 12, 198, 2, True), (2, 6, 197, 1, False), (2, 6, 198, 40, True)])
+def test_attention_rows_form_matches_packed(dev, B, H, N, NQ, gate):
+    """devit_attn_fwd_rows / devit_attn_bwd_rows on the first NQ query rows == the packed kernels on all rows, restricted to
+    those rows (forward) and fed an output gradient that is zero on the other rows (backward): bit for bit."""
+    from devit_amd import ops
+    from devit_amd._lib import call, ptr, stream_ptr
+    D = H * 64
+    g = torch.Generator(device=dev).manual_seed(7 + N + NQ)
+    qkv = (torch.randn((B * N, 3 * D), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    hg = (torch.rand(H, generator=g, device=dev) > 0.3).float() if gate else None
+    out = torch.zeros((B * N, D), dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros((B, H, N), dtype=torch.float32, device=dev)
+    call("devit_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(hg), B, N, H, 64, 0.125, 0, stream_ptr())
+    q_tok = qkv.view(B, N, 3 * D)[:, :NQ, :D].contiguous().view(B * NQ, D)
+    kv = qkv[:, D:].contiguous()
+    out_r = torch.zeros((B * NQ, D), dtype=torch.bfloat16, device=dev)
+    lse_r = torch.zeros((B, H, NQ), dtype=torch.float32, device=dev)
+    call("devit_attn_fwd_rows", ptr(q_tok), D, ptr(kv), 2 * D, ptr(out_r), ptr(lse_r), ptr(hg), B, NQ, N, H, 64, 0.125, 0,
+         stream_ptr())
+    assert torch.equal(out_r.view(B, NQ, D), out.view(B, N, D)[:, :NQ])
+    assert torch.equal(lse_r, lse[:, :, :NQ])
+    # backward
+    dout = torch.zeros((B, N, D), dtype=torch.bfloat16, device=dev)
+    dout[:, :NQ] = (torch.randn((B, NQ, D), generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    dqkv = torch.zeros_like(qkv)
+    call("devit_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(hg), None, ptr(dqkv), B, N, H, 64, 0.125, stream_ptr())
+    dq_r = torch.zeros((B * NQ, 3 * D), dtype=torch.bfloat16, device=dev)     # written with ld = 3D, like the tail does
+    dkv_r = torch.zeros((B * N, 2 * D), dtype=torch.bfloat16, device=dev)
+    dout_r = dout[:, :NQ].contiguous()
+    call("devit_attn_bwd_rows", ptr(q_tok), D, ptr(kv), 2 * D, ptr(out_r), ptr(dout_r), ptr(lse_r), ptr(hg), ptr(dq_r), 3 * D,
+         ptr(dkv_r), 2 * D, B, NQ, N, H, 64, 0.125, stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(dkv_r, dqkv[:, D:])
+    assert torch.equal(dq_r.view(B, NQ, 3 * D)[:, :, :D], dqkv.view(B, N, 3 * D)[:, :NQ, :D])
+    assert float(dqkv.view(B, N, 3 * D)[:, NQ:, :D].abs().max()) == 0.0       # untouched query rows get no dQ in the full kernel
+    assert float(dkv_r.abs().max()) > 0
+
+
+def _models(dev, name_s="dedeit"):
+    import devit_amd
+    st_s, st_t = O.make_state(GS, C, "S"), O.make_state(GT, C, "T")
+    s = devit_amd.create_model(name_s, num_classes=C, drop_path_rate=0.1, drop_block_rate=None)
+    t = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C)
+    if name_s == "dedeit":
+        s.load_state_dict(st_s)
+    t.load_state_dict(st_t)
+    for p in t.parameters():
+        p.requires_grad_(False)
+    return s.to(dev).train(), t.to(dev).eval()
+
+
+def _step(s, t, img, soft, dps, lean):
+    from devit_amd import de_vit, engine
+    de_vit.LEAN_TAIL = lean
+    try:
+        for p in s.parameters():
+            p.grad = None
+        out = engine.distill_forward(s, t, img, soft, gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0, dp_scales=dps)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return ({k: out[k].detach().clone() for k in ("loss", "cls_loss", "q_loss", "k_loss", "v_loss", "teacher_logits")},
+                tuple(x.detach().clone() for x in out["logits"]),
+                {n: p.grad.detach().clone() for n, p in s.named_parameters()})
+    finally:
+        de_vit.LEAN_TAIL = True
+
+
+def _dps(B, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    keep = torch.linspace(0, 0.1, 12)
+    dps = []
+    for i in range(12):
+        k = 1.0 - float(keep[i])
+        u = torch.rand((2, B), generator=g, device=dev)
+        sc = torch.floor(k + u) / k
+        dps.append((sc[0].contiguous(), sc[1].contiguous()))
+    return dps
+
+
+def _compare_steps(full, lean, tag, exact_losses=True):
+    (lf, of, gf), (ll, ol, gl) = full, lean
+    for k in lf:
+        if k == "teacher_logits" or exact_losses:
+            assert torch.equal(lf[k], ll[k]), (tag, k, lf[k], ll[k])     # forward: bit-identical
+        else:
+            # the loss SCALARS are summed over workgroups with fp32 atomics (csrc/losses.hip: 16 adds per scalar at B = 256;
+            # one workgroup at B = 8): not bit-reproducible between two runs of the same path either
+            assert chk(abs(float(lf[k]) - float(ll[k])) / abs(float(lf[k])), 1e-6), (tag, k, lf[k], ll[k])
+    for a, b in zip(of, ol):
+        assert torch.equal(a, b), tag
+    worst = ("", 0.0)
+    for n in gf:
+        assert gl[n].shape == gf[n].shape
+        e = relmax(gl[n], gf[n])
+        if e > worst[1]:
+            worst = (n, e)
+    assert chk(worst[1], 2e-5), (tag, worst)
+    return worst
+
+
+def test_lean_tail_step_equals_full_step_bs8(dev):
+    """DEKD step (DeiT-B -> dedeit, bs 8, recorded DropPath masks) with the last block on its token rows against the same
+    step with the full last block: logits, teacher logits and all five losses bit-identical; all 155 gradients within
+    2e-5 of their largest element."""
+    s, t = _models(dev)
+    img = torch.from_numpy(det_array("img8", (8, 3, 224, 224))).to(dev)
+    soft = torch.full((8, C), 0.1 / C, device=dev)
+    soft[torch.arange(8), torch.arange(8) % C] += 0.9
+    dps = _dps(8, dev, 5)
+    full = _step(s, t, img, soft, dps, lean=False)
+    lean = _step(s, t, img, soft, dps, lean=True)
+    assert len(full[2]) == 155
+    print("bs 8 lean vs full: worst gradient", _compare_steps(full, lean, "bs8"))
+    # and through the models' own forward (draws its own DropPath masks: eval mode for a deterministic comparison)
+    from devit_amd import de_vit
+    s.eval()
+    with torch.no_grad():
+        a = s(img)
+        with de_vit.lean_tail(s):
+            b = s(img)
+            d = s(img, distill_token=True)
+        f = s(img, distill_token=True)
+    assert torch.equal(a, b) and torch.equal(d["output"], a)
+    assert torch.equal(d["last_tokens"][0], f["last_tokens"][0]) and torch.equal(d["last_tokens"][1], f["last_tokens"][1])
+    # the flags that need the full last block switch the lean form off by themselves
+    with torch.no_grad(), de_vit.lean_tail(s):
+        e = s(img, output_qkv=True, output_encoders=True)
+    assert e["qkv"][11] is not None and e["encoder"][11].shape == (8, 198, 384)
+
+
+def test_lean_tail_nondistilled(dev):
+    """One class token (`devit`): the tail runs on one row per image."""
+    import devit_amd
+    from devit_amd import de_vit
+    torch.manual_seed(11)
+    m = devit_amd.create_model("devit", num_classes=10, drop_path_rate=0.0).to(dev).train()
+    img = torch.from_numpy(det_array("img8", (8, 3, 224, 224)))[:4].to(dev)
+    res = []
+    for lean in (False, True):
+        for p in m.parameters():
+            p.grad = None
+        de_vit.LEAN_TAIL = lean
+        try:
+            with de_vit.lean_tail(m):
+                out = m(img)
+            out.square().sum().backward()
+        finally:
+            de_vit.LEAN_TAIL = True
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    worst = max(relmax(res[1][1][n], res[0][1][n]) for n in res[0][1])
+    assert chk(worst, 2e-5), worst
+
+
+def test_lean_tail_step_equals_full_step_bs256(dev):
+    """The same at BASELINE's size (bs 256): the tail's GEMMs run at M = 512 rows against M = 50688."""
+    s, t = _models(dev)
+    torch.manual_seed(5)
+    g = torch.Generator(device=dev).manual_seed(77)
+    B = 256
+    img = torch.randn((B, 3, 224, 224), generator=g, device=dev)
+    y = torch.randint(0, C, (B,), generator=g, device=dev)
+    soft = torch.full((B, C), 0.1 / C, device=dev).scatter_(1, y[:, None], 0.9 + 0.1 / C)
+    dps = _dps(B, dev, 9)
+    full = _step(s, t, img, soft, dps, lean=False)
+    lean = _step(s, t, img, soft, dps, lean=True)
+    print("bs 256 lean vs full: worst gradient", _compare_steps(full, lean, "bs256", exact_losses=False))
