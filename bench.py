@@ -29,7 +29,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_IMG_STEP = 63.503      # BASELINE.md §2 (student fwd+bwd 27.740 + teacher fwd 35.311 + relation 0.452)
+GFLOP_PER_IMG_STEP = 63.503      # BASELINE.md §2 (student fwd+bwd 27.740 + teacher fwd 35.311 + relation 0.452): ALGORITHMIC
+# what the step EXECUTES: both models' last blocks run on their two token rows only (devit_amd.de_vit.lean_tail; the
+# reference computes and drops the other 196 rows): 63.503 - 2.431 (teacher) - 3 x 0.638 (student fwd + bwd)
+GFLOP_PER_IMG_EXECUTED = 59.159
 BF16_DENSE_PEAK = 2.5e15         # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 
 
@@ -111,16 +114,58 @@ def cpu_baseline(seconds):
                                 "sample": f"{m} fp32 `dedeit` eval forwards at bs 8 (BASELINE configs[0])"}}
 
 
-def pmc_traffic():
-    """Fabric-side bytes per launch of the dominant template (FETCH_SIZE x 2 + WRITE_SIZE), from the committed
-    rocprofv3 counter passes over this same command (tools/gpu_pmc_traffic.sh -> profiles/*_pmc_traffic.json; the
-    counters cannot be read from inside the process).  None when no summary is committed."""
+def kernel_sources_hash():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, devit_common.h, the C-ABI
+    header).  The counter summaries under profiles/ record it (tools/pmc_*.py); a summary taken on other kernels than the
+    ones this process runs is reported as stale instead of being passed off as a property of the current tree (there is no
+    .git on the GPU box to ask)."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "devit_amd", "csrc", "*.hip"))) + \
+        [os.path.join(ROOT, "devit_amd", "csrc", "devit_common.h"), os.path.join(ROOT, "include", "devit_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counter(pattern, key):
+    """(value, source) of the newest committed rocprofv3 counter summary matching profiles/<pattern> -- the counters cannot be
+    read from inside the process, so they come from separate `--pmc` passes over this same command (tools/gpu_pmc_*.sh).
+    value is None when no summary exists or when it was taken on different kernel sources (source says which)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
-        return json.load(f).get("traffic_bytes_per_launch")
+        d = json.load(f)
+    src = {"file": "profiles/" + os.path.basename(files[-1]), "kernel_sources_hash": d.get("kernel_sources_hash"),
+           "current_kernel_sources_hash": kernel_sources_hash()}
+    src["stale"] = src["kernel_sources_hash"] != src["current_kernel_sources_hash"]
+    return (None if src["stale"] else d.get(key)), src
+
+
+def parity_statement():
+    """Which tolerance the benchmarked kernels meet, from the newest committed profiles/*_parity_margins.json (written by the
+    `-m gpu` test session, tests/conftest.py): BASELINE.json asks for logits within 1e-3 rel; the bf16 kernels timed here do
+    not meet that, the exact-fp32 mode (never benchmarked) does."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_parity_margins.json")))
+    out = {"mode": "bf16", "logits_rel_to_max": None, "top1_exact": True, "bar": 1.5e-2,
+           "north_star_1e-3_met_by": 'precision="f32" (2e-6 measured; a few TFLOP/s, not benchmarked)', "source": None}
+    if not files:
+        return out
+    with open(files[-1]) as f:
+        rows = json.load(f)
+    vals = {}
+    for which in ("dedeit", "deitb"):
+        r = [x for x in rows if f"test_model_forward_vs_golden[{which}]" in x.get("test", "") and abs(x.get("bar", 0) - 1.5e-2) < 1e-9]
+        if r:
+            vals[which] = round(r[0]["value"], 6)
+    out["logits_rel_to_max"] = vals or None
+    out["source"] = "profiles/" + os.path.basename(files[-1]) + " (tests/test_gpu_model.py::test_model_forward_vs_golden, top-1 asserted bit-exact there)"
+    return out
 
 
 def self_launch(args):
@@ -184,17 +229,6 @@ def stub_main(args, rank, world, json_out):
                                    "loss": float(loss)}) + "\n")
         json_out.flush()
     dist.destroy_process_group()
-
-
-def pmc_mfma_busy():
-    """MFMA-pipe busy fraction of the dominant template from the committed rocprofv3 counter pass over this same command
-    (tools/gpu_pmc_mfma.sh -> profiles/*_pmc_mfma.json).  None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_mfma.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        return json.load(f).get("mfma_busy")
 
 
 def main():
@@ -380,12 +414,20 @@ def main():
         d[2] += 1
     dom = "A_row/B_row"
     fl, tm, cnt = by_t[dom]
+    traffic, traffic_src = committed_counter("*_pmc_traffic.json", "traffic_bytes_per_launch")
+    busy, busy_src = committed_counter("*_pmc_mfma.json", "mfma_busy")
+    from devit_amd import de_vit
+    executed = GFLOP_PER_IMG_EXECUTED if de_vit.LEAN_TAIL else GFLOP_PER_IMG_STEP
     roof = {"bound": "mfma", "kernel": "gemm_kernel<*, A_row, B_row, *> (persistent 128x128 / 256x256 x64 bf16 MFMA tiles; fwd Linear layers of teacher + student)",
             "achieved": round(fl / tm / 1e12, 2), "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": round(fl / tm / BF16_DENSE_PEAK, 4), "traffic": pmc_traffic(), "mfma_busy": pmc_mfma_busy(),
+            "frac": round(fl / tm / BF16_DENSE_PEAK, 4),
+            "achieved_counts": "FLOPs the launches execute (2 M N K of each launch, padded rows included) / their event time",
+            "traffic": traffic, "traffic_source": traffic_src, "mfma_busy": busy, "mfma_busy_source": busy_src,
             "launches_per_step": cnt, "avg_launch_us": round(tm / cnt * 1e6, 2),
             "gflop_per_launch_avg": round(fl / cnt / 1e9, 3),
             "step_frac": round(img_per_s / world * GFLOP_PER_IMG_STEP * 1e9 / BF16_DENSE_PEAK, 4),
+            "step_frac_counts": "ALGORITHMIC FLOPs of the reference's step (63.503 GFLOP per image) x images/sec / peak",
+            "step_frac_executed": round(img_per_s / world * executed * 1e9 / BF16_DENSE_PEAK, 4),
             "other_templates": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "launches": v[2],
                                     "ms_per_step": round(v[1] * 1e3, 3)} for k, v in by_t.items() if k != dom},
             "gemm_ms_per_step": round(sum(v[1] for v in by_t.values()) * 1e3, 3),
@@ -403,6 +445,12 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
             "host_ms_per_step_idle_queue": round(host_step_ms, 3),
             "higher_is_better": True, "scaling": "weak",
+            "algorithmic_gflop_per_img": GFLOP_PER_IMG_STEP, "executed_gflop_per_img": executed,
+            "timing_protocol": f"{args.warmup} untimed steps, then {args.steps} steps wall-clocked between barrier + "
+                               "torch.cuda.synchronize() on both sides, max over ranks, mean per step (SURVEY 8d's median-of-50 "
+                               "protocol is not what the driver runs); roofline / hbm_bound_kernels from one extra instrumented "
+                               "serialized step (HIP events on the launch stream)",
+            "parity": parity_statement(),
             "vs_baseline": None, "dtype": "bf16", "teacher_dtype": args.teacher_precision, "data": "synthetic, pinned host batches through PCIe every step" if args.host_input else "synthetic",
             "config": {"workload": f"distill_sub step dedeit<-deit_base_distilled_patch16_224, num_division=4 "
                                    f"(C={C}), bs={B}/GPU, 224x224, hard distillation, drop_path 0.1, AdamW+EMA",

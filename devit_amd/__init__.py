@@ -6,7 +6,8 @@ Importing the package needs neither a GPU nor the shared library; running any op
 """
 from . import de_vit, losses, registry  # noqa: F401
 from .de_vit import Attention, Block, Mlp, VisionTransformer, model_config  # noqa: F401
-from .losses import DistillLoss, SoftTargetCrossEntropy, feature_relation_loss, relation_losses_packed  # noqa: F401
+from .losses import (DistillLoss, LabelSmoothingCrossEntropy, SoftTargetCrossEntropy, feature_relation_loss,  # noqa: F401
+                     relation_losses_packed)
 from .registry import create_model, register_model  # noqa: F401
 
 __version__ = "0.1.0"

@@ -158,12 +158,12 @@ extern "C" int devit_block_acts_sizes(int B, int N, int D, int Da, int Hd, int f
 extern "C" int devit_block_bwd_sizes(int B, int N, int D, int Da, int Hd, size_t* sizes) {
   DEVIT_CHECK(sizes != nullptr, DEVIT_ERR_ARG, "devit_block_bwd_sizes: null");
   TRY(check_dims(B, N, D, Da, Hd));
-  DEVIT_CHECK(Da == D, DEVIT_ERR_SHAPE, "devit_block_bwd: compacted blocks (attn_width != D) are inference-only");
   const size_t M = (size_t)B * N, Mp = pad_rows((int)M);
   sizes[DEVIT_BWD_DH_PRE] = Mp * Hd * 2;
-  sizes[DEVIT_BWD_DLN2] = sizes[DEVIT_BWD_G1] = sizes[DEVIT_BWD_DATTN] = sizes[DEVIT_BWD_DLN1] = Mp * D * 2;
+  sizes[DEVIT_BWD_DLN2] = sizes[DEVIT_BWD_G1] = sizes[DEVIT_BWD_DLN1] = Mp * D * 2;
+  sizes[DEVIT_BWD_DATTN] = Mp * (size_t)Da * 2;
   sizes[DEVIT_BWD_DX1] = M * D * 4;
-  sizes[DEVIT_BWD_DQKV] = Mp * 3 * (size_t)D * 2;
+  sizes[DEVIT_BWD_DQKV] = Mp * 3 * (size_t)Da * 2;
   sizes[DEVIT_BWD_LNWS] = devit_layernorm_bwd_workspace((int)M, D);
   for (int i = 0; i < DEVIT_BWD_COUNT; ++i) sizes[i] = align256(sizes[i]);
   return DEVIT_OK;
@@ -187,9 +187,9 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
   const devit_block_weights& w = *wp;
   const devit_block_acts& a = *ap;
   const devit_block_wgrads& g = *gp;
-  const int Hd = w.hidden, H = w.num_heads;
-  TRY(check_dims(B, N, D, w.attn_width, Hd));
-  DEVIT_CHECK(w.attn_width == D && H * 64 == D, DEVIT_ERR_SHAPE, "devit_block_bwd: compacted blocks are inference-only");
+  const int Hd = w.hidden, H = w.num_heads, Da = w.attn_width;   // Da = H * 64 (< D when heads were compacted away)
+  TRY(check_dims(B, N, D, Da, Hd));
+  DEVIT_CHECK(H > 0 && Da == H * 64, DEVIT_ERR_SHAPE, "devit_block_bwd: attn_width %d != heads %d * 64", Da, H);
   DEVIT_CHECK(a.flags & DEVIT_BLK_SAVE, DEVIT_ERR_ARG, "devit_block_bwd: the forward ran without DEVIT_BLK_SAVE");
   DEVIT_CHECK(w.dtype16 == 0, DEVIT_ERR_ARG, "devit_block_bwd: f16 blocks have no backward");
   DEVIT_CHECK(io->dx && io->g2 && io->dx_in, DEVIT_ERR_ARG, "devit_block_bwd: dx / g2 / dx_in");
@@ -208,8 +208,8 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
   TRY(zero_pad(c, dh_pre, Hd, 2));
   TRY(zero_pad(c, dln2, D, 2));
   TRY(zero_pad(c, g1, D, 2));
-  TRY(zero_pad(c, dattn, D, 2));
-  TRY(zero_pad(c, dqkv, 3 * D, 2));
+  TRY(zero_pad(c, dattn, Da, 2));
+  TRY(zero_pad(c, dqkv, 3 * Da, 2));
   TRY(zero_pad(c, dln1, D, 2));
   TRY(zero_pad(c, io->g_prev, D, 2));
   // ---- MLP branch: x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2))).  The weight gradient that only needs g2 first, then
@@ -228,12 +228,12 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
                           (const float*)b[DEVIT_ACT_RSTD2], w.n2w, io->dx, dx1, g1, a.dp1, N, g.n2w, g.n2b, g.proj_b, 1,
                           io->ws[DEVIT_BWD_LNWS], io->lnws_bytes, stream));
   // ---- attention branch: x1 = x + dp1 * proj(gate * attn(qkv(ln1)))
-  TRY(linear_dgrad(c, g1, w.proj_w16, D, D, make_ep(DEVIT_EPI_STORE_BF16, dattn, D, c.M)));
-  TRY(linear_wgrad(c, g1, b[DEVIT_ACT_ATTN_O], g.proj_w, nullptr, D, D));
+  TRY(linear_dgrad(c, g1, w.proj_w16, D, Da, make_ep(DEVIT_EPI_STORE_BF16, dattn, Da, c.M)));
+  TRY(linear_wgrad(c, g1, b[DEVIT_ACT_ATTN_O], g.proj_w, nullptr, D, Da));
   TRY(devit_attn_bwd(b[DEVIT_ACT_QKV], b[DEVIT_ACT_ATTN_O], dattn, (const float*)b[DEVIT_ACT_LSE], w.head_gate, io->dqkv_add,
                      dqkv, B, N, H, 64, 0.125f, stream));
-  TRY(linear_dgrad(c, dqkv, w.qkv_w16, 3 * D, D, make_ep(DEVIT_EPI_STORE_BF16, dln1, D, c.M)));
-  TRY(linear_wgrad(c, dqkv, b[DEVIT_ACT_LN1], g.qkv_w, g.qkv_b, 3 * D, D));
+  TRY(linear_dgrad(c, dqkv, w.qkv_w16, 3 * Da, D, make_ep(DEVIT_EPI_STORE_BF16, dln1, D, c.M)));
+  TRY(linear_wgrad(c, dqkv, b[DEVIT_ACT_LN1], g.qkv_w, g.qkv_b, 3 * Da, D));
   // LN1 backward: dx_in = dx1 + LN'(dln1); g_prev = bf16(prev_dp2 * dx_in) (+ the block below's fc2 bias gradient)
   TRY(devit_layernorm_bwd(dln1, 0, a.x, c.M, D, 0, 0, (const float*)b[DEVIT_ACT_MEAN1], (const float*)b[DEVIT_ACT_RSTD1],
                           w.n1w, dx1, io->dx_in, io->g_prev, io->prev_dp2, N, g.n1w, g.n1b,

@@ -279,3 +279,8 @@ def broadcast_module(module, src=0, group=None):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=group)
+    # writing through .data does not bump version counters: drop every cache keyed on them (16-bit GEMM copies, block
+    # parameter views), so a forward that ran before the broadcast cannot leave stale weights behind
+    for m in module.modules():
+        for k in ("_w16", "_w16h", "_bp_cache"):
+            m.__dict__.pop(k, None)

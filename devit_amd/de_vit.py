@@ -47,6 +47,8 @@ class _Gated:
         self._gate = torch.ones(n)
         self._gate_dev = None
         self._gate_ones = True
+        self._gate_version = 0        # bumped by every assignment: cache keys use it, never id() (ids of freed tensors are reused)
+        self._gate_seen = (0, self._gate._version)
 
     @property
     def gate(self):
@@ -57,9 +59,17 @@ class _Gated:
         self._gate = value
         self._gate_dev = None
         self._gate_ones = None        # unknown until the next forward looks (the shrink code ASSIGNS gates, imp_rank.py:65-71)
+        self._gate_version += 1
+
+    def gate_key(self):
+        """Changes whenever the gate was assigned or written in place."""
+        return (self._gate_version, self._gate._version)
 
     def gate_on(self, device):
         g = self._gate
+        if self._gate_seen != self.gate_key():      # assigned, or modified in place (m.gate[j] = 0), since the last look
+            self._gate_seen = self.gate_key()
+            self._gate_dev, self._gate_ones = None, None
         if self._gate_ones is None:
             self._gate_ones = bool((g == 1).all())
         if self._gate_ones:
@@ -143,15 +153,22 @@ class Block(nn.Module):
         c = getattr(self, "_compact", None)
         a, m_ = self.attn, self.mlp
         wk = "_w16h" if f16 else "_w16"
-        key = (device, self.training, self.drop_prob, f16, id(c), id(a._gate), id(m_._gate),
-               id(a.qkv.__dict__.get(wk)), id(a.proj.__dict__.get(wk)), id(m_.fc1.__dict__.get(wk)),
-               id(m_.fc2.__dict__.get(wk)), a.qkv.weight._version, a.proj.weight._version, m_.fc1.weight._version, m_.fc2.weight._version,
-               a.qkv.weight.data_ptr(), a.proj.weight.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc2.weight.data_ptr())
+        def w16_ptr(lin):      # the cached BlockParams holds this tensor, so its address cannot be handed out again meanwhile
+            t = lin.__dict__.get(wk)
+            return t[1].data_ptr() if t is not None else 0
+        def key():
+            return (device, self.training, self.drop_prob, f16, getattr(self, "_compact_version", 0), c is not None,
+                    a.gate_key(), m_.gate_key(), w16_ptr(a.qkv), w16_ptr(a.proj), w16_ptr(m_.fc1), w16_ptr(m_.fc2),
+                    a.qkv.weight._version, a.proj.weight._version, m_.fc1.weight._version, m_.fc2.weight._version,
+                    a.qkv.weight.data_ptr(), a.proj.weight.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc2.weight.data_ptr())
+        if c is not None and c.get("trainable") and self.training:
+            from . import shrink         # the optimizer rewrote the masters (and their bf16 copies) since the last forward
+            shrink.refresh_compact(self)
         cached = getattr(self, "_bp_cache", None)
-        if cached is not None and cached[0] == key:
+        if cached is not None and cached[0] == key():
             return cached[1]
         bp = self._build_block_params(device, f16)
-        self._bp_cache = (key, bp)
+        self._bp_cache = (key(), bp)         # (the build may have made the 16-bit copies: key taken after it)
         return bp
 
     def _build_block_params(self, device, f16=False):
@@ -165,8 +182,13 @@ class Block(nn.Module):
             bp.qkv_w = bp.proj_w = bp.fc1_w = bp.fc2_w = None
             bp.qkv_b, bp.proj_b, bp.fc1_b, bp.fc2_b = c["qkv_b"], self.attn.proj.bias, c["fc1_b"], self.mlp.fc2.bias
             bp.qkv_w16, bp.proj_w16, bp.fc1_w16, bp.fc2_w16 = c["qkv_w16"], c["proj_w16"], c["fc1_w16"], c["fc2_w16"]
-            bp.num_heads, bp.head_gate, bp.neuron_gate = c["num_heads"], None, None
-            bp.dp_prob, bp.module, bp.compacted = 0., self, True
+            bp.num_heads, bp.neuron_gate = c["num_heads"], None
+            bp.head_gate = None if c.get("heads_compacted", True) else self.attn.gate_on(device)
+            bp.dp_prob, bp.module, bp.compacted = (self.drop_prob if self.training else 0.), self, True
+            bp.masters = bp.finish = None
+            if c.get("trainable"):   # training through the compacted block: compact weight gradients -> the masters'
+                from . import shrink
+                shrink.attach_training(self, bp, c)
             return bp
         bp.n1w, bp.n1b = self.norm1.weight, self.norm1.bias
         bp.qkv_w, bp.qkv_b = self.attn.qkv.weight, self.attn.qkv.bias
@@ -180,6 +202,7 @@ class Block(nn.Module):
         bp.head_gate, bp.neuron_gate = self.attn.gate_on(device), self.mlp.gate_on(device)
         bp.dp_prob = self.drop_prob if self.training else 0.
         bp.module = self
+        bp.masters = bp.finish = None
         if bp.qkv_b is None:
             raise NotImplementedError("qkv_bias=False is not used by any registered DeViT model")
         return bp

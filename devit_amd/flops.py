@@ -6,7 +6,8 @@ core/shrink_imp.py:144), DeiT-B 35.127656448 / 86.540008, `dedeit` at 0.3 / 0.3 
 bench.py's roofline uses the same formula at the benchmark's geometry (N = 198 tokens of the distilled models, C = 25):
 teacher forward 35.311, student forward 9.247 GFLOP per image."""
 
-__all__ = ["forward_gflops", "params_m", "macs_g", "step_gflops_per_image", "RELATION_LOSS_GFLOP"]
+__all__ = ["forward_gflops", "params_m", "macs_g", "step_gflops_per_image", "RELATION_LOSS_GFLOP", "lean_tail_skipped_gflops",
+           "step_gflops_per_image_executed"]
 
 # q/k/v feature-relation losses per image (BASELINE.md section 2): Gram matrices of both models forward (3 components x
 # 2 * 198^2 * (768 + 384)) and the student-side backward
@@ -66,3 +67,22 @@ def step_gflops_per_image(num_class=25, tokens=198):
     teacher = forward_gflops(seq_length=tokens, num_class=num_class)
     student = forward_gflops(emb=384, head=6, seq_length=tokens, num_class=num_class)
     return teacher + 3.0 * student + RELATION_LOSS_GFLOP
+
+
+def lean_tail_skipped_gflops(emb=768, mlp_ratio=4, tokens=198, ntok=2):
+    """Forward GFLOPs per image of the LAST block that the lean tail (devit_amd.de_vit.lean_tail) does not execute: the
+    Q projection, the attention of, the output projection and both MLP matrices on the tokens - ntok rows whose results
+    nothing reads (models/de_vit.py:286-288 keeps x[:, 0] and x[:, 1]); K and V of every row are still computed."""
+    dead = tokens - ntok
+    hidden = int(mlp_ratio * emb)
+    return (2.0 * dead * emb * emb            # Q projection
+            + 4.0 * dead * tokens * emb       # q k^T and (q k^T) v over all heads
+            + 2.0 * dead * emb * emb          # output projection
+            + 4.0 * dead * emb * hidden) / 1e9
+
+
+def step_gflops_per_image_executed(num_class=25, tokens=198):
+    """step_gflops_per_image minus what the lean last blocks skip (teacher forward; student forward and backward):
+    the FLOPs the step EXECUTES.  63.503 - 2.431 - 3 * 0.638 = 59.159 at C = 25."""
+    return (step_gflops_per_image(num_class, tokens) - lean_tail_skipped_gflops(768, 4, tokens, 2)
+            - 3.0 * lean_tail_skipped_gflops(384, 4, tokens, 2))

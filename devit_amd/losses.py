@@ -20,15 +20,30 @@ class SoftTargetCrossEntropy(nn.Module):
         return ops.ClsDistillLossFn.apply(x, x, zero, target, "none", 0.0, 1.0)
 
 
+def smoothed_one_hot(labels, num_classes, smoothing):
+    """[B, C] fp32 rows with 1 - smoothing + smoothing / C on the label and smoothing / C elsewhere: soft-target CE on these rows
+    == LabelSmoothingCrossEntropy(smoothing) (utils/losses.py:25-31: confidence * nll + smoothing * mean(-log p))."""
+    off = smoothing / num_classes
+    return torch.full((labels.shape[0], num_classes), off, dtype=torch.float32, device=labels.device) \
+        .scatter_(1, labels.long()[:, None], 1.0 - smoothing + off)
+
+
 class DistillLoss(nn.Module):
-    """utils/losses.py:122-177.  `labels` are the soft [B, C] targets produced by Mixup (engine.py:66); hard
-    int64 labels are expanded to one-hot rows (== nn.CrossEntropyLoss, distill_sub.py:352)."""
+    """utils/losses.py:122-177 with any of the three base criteria distill_sub.py:345-352 can pick: SoftTargetCrossEntropy
+    (mixup on: `labels` are the soft [B, C] targets of engine.py:66), LabelSmoothingCrossEntropy(smoothing) (mixup off,
+    --smoothing > 0) and nn.CrossEntropyLoss (both off) on int64 labels -- the last two are the soft-target kernel on
+    smoothed / plain one-hot rows."""
 
     def __init__(self, base_criterion, distillation_type, alpha, tau):
         super().__init__()
         assert distillation_type in ['none', 'soft', 'hard']
-        if not isinstance(base_criterion, (SoftTargetCrossEntropy, nn.CrossEntropyLoss)):
-            raise NotImplementedError("DistillLoss is fused for SoftTargetCrossEntropy / CrossEntropyLoss base criteria")
+        if not isinstance(base_criterion, (SoftTargetCrossEntropy, nn.CrossEntropyLoss, LabelSmoothingCrossEntropy)):
+            raise NotImplementedError("DistillLoss is fused for the base criteria distill_sub.py:345-352 selects: "
+                                      "SoftTargetCrossEntropy, LabelSmoothingCrossEntropy, nn.CrossEntropyLoss")
+        if isinstance(base_criterion, nn.CrossEntropyLoss) and (
+                base_criterion.weight is not None or base_criterion.label_smoothing or base_criterion.reduction != "mean"
+                or base_criterion.ignore_index != -100):
+            raise NotImplementedError("DistillLoss: nn.CrossEntropyLoss() with default arguments only (distill_sub.py:352)")
         self.base_criterion = base_criterion
         self.distillation_type = distillation_type
         self.alpha = alpha
@@ -39,8 +54,13 @@ class DistillLoss(nn.Module):
             outputs, outputs_kd = outputs         # (cls head, dist head), utils/losses.py:164-167
         else:
             outputs_kd = outputs
-        if labels.dtype in (torch.int64, torch.int32):
-            labels = torch.nn.functional.one_hot(labels.long(), outputs.shape[1]).to(outputs.dtype)
+        hard = labels.dtype in (torch.int64, torch.int32)
+        if isinstance(self.base_criterion, LabelSmoothingCrossEntropy):
+            if not hard:
+                raise ValueError("LabelSmoothingCrossEntropy takes int64 class labels (utils/losses.py:23 gathers by them)")
+            labels = smoothed_one_hot(labels, outputs.shape[1], self.base_criterion.smoothing)
+        elif hard:
+            labels = smoothed_one_hot(labels, outputs.shape[1], 0.0)
         return ops.ClsDistillLossFn.apply(outputs, outputs_kd, teacher_outputs, labels, self.distillation_type,
                                           float(self.alpha), float(self.tau))
 
@@ -138,16 +158,10 @@ class DistillationLoss(nn.Module):
                                       "dict) -- DESIGN.md section 9")
         self.base_criterion, self.teacher_model = base_criterion, teacher_model
         self.distillation_type, self.alpha, self.tau = distillation_type, alpha, tau
-        # LabelSmoothingCrossEntropy (train_subdata.py:411-416 without mixup) == soft-target CE on smoothed one-hot rows
-        self._smoothing = base_criterion.smoothing if isinstance(base_criterion, LabelSmoothingCrossEntropy) else None
-        fused = SoftTargetCrossEntropy() if self._smoothing is not None else base_criterion
-        self._loss = DistillLoss(fused, distillation_type, alpha, tau)
+        # LabelSmoothingCrossEntropy (train_subdata.py:411-416 without mixup): DistillLoss smooths the one-hot rows itself
+        self._loss = DistillLoss(base_criterion, distillation_type, alpha, tau)
 
     def forward(self, inputs, outputs, labels, token_outputs=None):
-        if self._smoothing is not None and labels.dtype in (torch.int64, torch.int32):
-            C = (outputs if isinstance(outputs, torch.Tensor) else outputs[0]).shape[-1]
-            labels = torch.full((labels.shape[0], C), self._smoothing / C, dtype=torch.float32, device=labels.device) \
-                .scatter_(1, labels.long()[:, None], 1.0 - self._smoothing + self._smoothing / C)
         if self.distillation_type == 'none':
             logits = outputs if isinstance(outputs, torch.Tensor) else outputs[0]
             return self._loss((logits, logits), None, labels)
@@ -168,8 +182,7 @@ class LabelSmoothingCrossEntropy(nn.Module):
         self.confidence = 1. - smoothing
 
     def forward(self, x, target):
-        C = x.shape[-1]
-        soft = torch.full_like(x, self.smoothing / C).scatter_(1, target[:, None], self.confidence + self.smoothing / C)
+        soft = smoothed_one_hot(target, x.shape[-1], self.smoothing)
         return ops.ClsDistillLossFn.apply(x, x, torch.zeros_like(x), soft, "none", 0.0, 1.0)
 
 
@@ -201,8 +214,7 @@ class EnsLoss(nn.Module):
             raise NotImplementedError("EnsLoss: only loss_type='mse' is on the DeViT path (ensemble.py default)")
         self.base_criterion, self.teacher_model, self.model = base_criterion, teacher_model, model
         self.distillation_type, self.alpha, self.tau = distillation_type, alpha, tau
-        self._cls = DistillLoss(base_criterion if isinstance(base_criterion, (SoftTargetCrossEntropy, nn.CrossEntropyLoss))
-                                else SoftTargetCrossEntropy(), distillation_type, alpha, tau)
+        self._cls = DistillLoss(base_criterion, distillation_type, alpha, tau)     # raises for a base criterion it does not fuse
 
     def forward(self, inputs, stu_outputs, labels):
         if self.distillation_type == 'none':

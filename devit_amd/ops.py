@@ -188,10 +188,24 @@ def _ones1(dev):
     return t
 
 
+class GradSlot:
+    """Stands where a parameter stands in BlockParams when the block runs on COMPACTED weights (shrink.compact): the
+    weight-gradient GEMMs accumulate into `.grad` [compact shape] and BlockParams.finish_grads() adds it into the kept
+    rows / columns of the fp32 master's gradient."""
+    __slots__ = ("shape", "device", "grad", "requires_grad")
+
+    def __init__(self, shape, device):
+        self.shape, self.device, self.grad, self.requires_grad = tuple(shape), device, None, False
+
+
 def grad_buf(p):
     """fp32 accumulation buffer of a parameter (== param.grad, zero-initialised on first use)."""
+    p = getattr(p, "slot", p)             # a compact bias: the value the kernels read + the slot its gradient goes to
     if p.grad is None:
-        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        if isinstance(p, GradSlot):
+            p.grad = torch.zeros(p.shape, dtype=F32, device=p.device)
+        else:
+            p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
     return p.grad
 
 
@@ -207,11 +221,20 @@ class BlockParams:
     """fp32 parameters + cached bf16 GEMM copies of one Block (see de_vit.Block)."""
     __slots__ = ("n1w", "n1b", "qkv_w", "qkv_b", "proj_w", "proj_b", "n2w", "n2b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
                  "qkv_w16", "proj_w16", "fc1_w16", "fc2_w16", "num_heads", "head_gate", "neuron_gate", "dp_prob",
-                 "module", "compacted")
+                 "module", "compacted", "masters", "finish")
 
     def all_params(self):
+        """The nn.Parameters behind this block (the masters when the block runs compacted)."""
+        if getattr(self, "masters", None) is not None:
+            return self.masters
         return [self.n1w, self.n1b, self.qkv_w, self.qkv_b, self.proj_w, self.proj_b, self.n2w, self.n2b, self.fc1_w,
                 self.fc1_b, self.fc2_w, self.fc2_b]
+
+    def finish_grads(self):
+        """After the block's backward: compacted blocks add their compact weight gradients into the masters'."""
+        f = getattr(self, "finish", None)
+        if f is not None:
+            f()
 
 
 class EncoderCfg:
@@ -286,6 +309,7 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, p
     B, N, D = dx.shape
     M, H, dev = B * N, bp.num_heads, dx.device
     Hd = bp.fc1_w.shape[0]
+    Da = H * 64                      # attention width (< D when heads were compacted away)
     # ---- MLP branch: x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2)))
     # Order: the weight gradient that only needs g2 first, then dh_pre's producer and its consumers back to back (dh_pre is
     # 156 MB at B = 256; these GEMMs run 1.2-1.7x slower on operands from cold HBM than from the 256 MB Infinity Cache,
@@ -305,14 +329,14 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, p
     # ---- attention branch: x1 = x + dp1 * proj(gate * attn(qkv(ln1)))
     if datt is not None:  # gradient flowing into the exposed 'attention' output (pre-residual, post-proj)
         g1 = g1 + _pad_like(datt, g1)
-    dattn = rows_alloc(M, D, BF16, dev)
+    dattn = rows_alloc(M, Da, BF16, dev)
     linear_dgrad(g1, bp.proj_w16, M, out=dattn)
     linear_wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), None if fuse_pb else grad_buf(bp.proj_b), M)
-    dqkv = rows_alloc(M, 3 * D, BF16, dev)
+    dqkv = rows_alloc(M, 3 * Da, BF16, dev)
     # algorithmic bytes: q, k, v, o, do in; dq, dk, dv out (+ the relation-loss gradient that is added in)
-    _bracketed("attention_bwd", M * D * 2 * (8 + (3 if dqkv_add is not None else 0)), lambda: call(
+    _bracketed("attention_bwd", M * Da * 2 * (8 + (3 if dqkv_add is not None else 0)), lambda: call(
         "devit_attn_bwd", ptr(s["qkv"]), ptr(s["attn_o"]), ptr(dattn), ptr(s["lse"]), ptr(bp.head_gate),
-        ptr(dqkv_add), ptr(dqkv), B, N, H, D // H, (D // H) ** -0.5, stream_ptr()))
+        ptr(dqkv_add), ptr(dqkv), B, N, H, 64, 0.125, stream_ptr()))
     dln1 = rows_alloc(M, D, BF16, dev)
     linear_dgrad(dqkv, bp.qkv_w16, M, out=dln1)
     linear_wgrad(dqkv, s["ln1"], grad_buf(bp.qkv_w), grad_buf(bp.qkv_b), M)
@@ -489,17 +513,22 @@ def _act_sizes(B, N, D, Da, Hd, flags):
     return v
 
 
-def _bwd_sizes(B, N, D, Hd):
-    key = ("b", B, N, D, Hd)
+def _bwd_sizes(B, N, D, widths):
+    """Transient buffers of devit_block_bwd, sized for the widest of `widths` = {(attn_width, hidden)} (compacted blocks of one
+    model differ)."""
+    key = ("b", B, N, D, tuple(sorted(widths)))
     v = _sizes_cache.get(key)
     if v is None:
-        sz = (C.c_size_t * L.BWD_COUNT)()
-        call("devit_block_bwd_sizes", B, N, D, D, Hd, sz)
+        mx = [0] * L.BWD_COUNT
+        for Da, Hd in widths:
+            sz = (C.c_size_t * L.BWD_COUNT)()
+            call("devit_block_bwd_sizes", B, N, D, Da, Hd, sz)
+            mx = [max(a, b) for a, b in zip(mx, sz)]
         offs, off = [], 0
-        for n in sz:
+        for n in mx:
             offs.append(off)
             off += n
-        v = _sizes_cache[key] = (list(sz), offs, off)
+        v = _sizes_cache[key] = (mx, offs, off)
     return v
 
 
@@ -581,8 +610,7 @@ def _encoder_backward_composite(run, cfg, dx, dqkvs):
     B, N, D = run.dims
     M, dev, nb = B * N, dx.device, run.nb
     mp = pad_rows(M)
-    Hd = run.weights[0].hidden
-    sz, offs, tot = _bwd_sizes(B, N, D, Hd)
+    sz, offs, tot = _bwd_sizes(B, N, D, {(run.weights[i].attn_width, run.weights[i].hidden) for i in range(nb)})
     # transient buffers shared by all blocks + two fp32 dx and two bf16 g buffers that alternate
     dxb, gb = M * D * 4, mp * D * 2
     ws = torch.empty(tot + 2 * dxb + 2 * gb, dtype=torch.uint8, device=dev)
@@ -601,8 +629,6 @@ def _encoder_backward_composite(run, cfg, dx, dqkvs):
     st = stream_ptr()
     for i in range(nb - 1, -1, -1):
         bp = cfg.blocks[i]
-        if run.weights[i].hidden != Hd:
-            raise L.DevitError("composite backward: blocks of different hidden width")
         dq = dqkvs[i] if dqkvs else None
         if dq is not None:
             dq = dq.contiguous()
@@ -618,6 +644,7 @@ def _encoder_backward_composite(run, cfg, dx, dqkvs):
         wg = _wgrads_struct(bp)
         call("devit_block_bwd", C.byref(run.weights[i]), C.byref(run.acts[i]), C.byref(wg), C.byref(io), B, N, D, cfg.eps, st)
         cur_dx, cur_g, g_bias_done = dx_ptrs[out_slot], cur_g ^ 1, 1 if prev is not None else 0
+        bp.finish_grads()
         if cfg.grad_ready is not None:
             cfg.grad_ready(bp.all_params())
     o = tot + (0 if cur_dx == dx_ptrs[0] else dxb)
@@ -632,9 +659,9 @@ class EncoderFn(torch.autograd.Function):
         L.require_device(x)
         x = x.contiguous()
         need_grad = cfg.grad_enabled and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
-        if need_grad and any(getattr(bp, "compacted", False) for bp in cfg.blocks):
-            raise L.DevitError("a compacted model (devit_amd.shrink.compact) is inference-only: run it under "
-                               "torch.no_grad() or call shrink.uncompact(model) before training")
+        if need_grad and any(getattr(bp, "compacted", False) and getattr(bp, "masters", None) is None for bp in cfg.blocks):
+            raise L.DevitError("this model was compacted for inference (shrink.compact(model)): run it under torch.no_grad(), "
+                               "or compact it with shrink.compact(model, trainable=True) to train through the compacted blocks")
         ctx.run = None
         nb = len(cfg.blocks)
         # lean tail (EncoderCfg.lean_tokens): the last block runs on the token rows only
@@ -730,6 +757,7 @@ class EncoderFn(torch.autograd.Function):
                 dx = dx + extra
                 g = scale_cast(dx, prev_dp2, N)
             saved[i] = None
+            bp.finish_grads()
             if cfg.grad_ready is not None:
                 cfg.grad_ready(bp.all_params())
         return (dx, None) + (None,) * nparams

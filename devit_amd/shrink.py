@@ -30,15 +30,16 @@ def _round_up(n, m):
 
 
 @torch.no_grad()
-def compact_block_weights(blk):
+def compact_block_weights(blk, heads=True):
     """fp32 compacted weights of one Block from its current gates (pure tensor indexing: runs on any device).
     Returns dict(num_heads, qkv_w [3*64*Hr, D], qkv_b, proj_w [D, 64*Hr], fc1_w [Nr, D], fc1_b, fc2_w [D, Nr],
-    kept_heads, kept_neurons)."""
+    kept_heads, kept_neurons).  heads=False: only the MLP is compacted; all heads stay in the qkv / proj GEMMs and the
+    head gate keeps acting at run time (a block whose q/k/v of ALL heads are read, see compact())."""
     attn, mlp = blk.attn, blk.mlp
     dev = attn.qkv.weight.device
     D, H = attn.qkv.weight.shape[1], attn.num_heads
     hd = attn.qkv.weight.shape[0] // (3 * H)
-    hg = attn.gate.detach().float().cpu().reshape(-1)
+    hg = attn.gate.detach().float().cpu().reshape(-1) if heads else torch.ones(H)
     keep_h = torch.nonzero(hg != 0).reshape(-1)
     Hr = max(2, _round_up(len(keep_h), 2))                       # heads run (3 * 64 * Hr must be a multiple of 128)
     qw = attn.qkv.weight.detach().float().view(3, H, hd, D)
@@ -67,23 +68,130 @@ def compact_block_weights(blk):
 
 
 @torch.no_grad()
-def compact(model):
+def compact(model, trainable=False):
     """Build the compacted weights of every block of `model` (a devit_amd VisionTransformer, MultiViT sub-models
-    included) from its current gates.  Returns [(kept heads, heads run, kept neurons, neurons run)] per block."""
+    included) from its current gates.  Returns [(kept heads, heads run, kept neurons, neurons run)] per block.
+
+    trainable=True: the model can be TRAINED through the compacted blocks -- what distill_sub.py:384-401 does with the
+    masked model (rank one batch, set the gates, train), at the shrunk model's FLOPs.  Needs 0/1 gates (the masks of
+    core/imp_rank.py:50-71,132-153).  The fp32 masters stay the parameters: every training forward re-gathers the kept
+    rows / columns from their current bf16 copies (refresh_compact), the backward's weight-gradient GEMMs run at the
+    compact shapes and their results are added into the kept rows / columns of the masters' gradients; masked units get
+    exact-zero gradients, as in the masked model (their activations are multiplied by a zero gate there)."""
     report = []
+    # DEKD reads q/k/v of ALL heads of the middle block (engine.py:91-92; the gate of models/de_vit.py:77-79 acts on the head
+    # OUTPUTS, so a masked head's q/k/v still enter -- and get gradients from -- the relation loss): when training, that
+    # block keeps every head in its GEMMs and masks at run time
+    keep_heads = set()
+    if trainable:
+        for m in model.modules():
+            if type(m).__name__ == "VisionTransformer" and len(m.blocks) >= 2:
+                keep_heads.add(id(m.blocks[len(m.blocks) // 2 - 1]))
     for blk in _blocks(model):
-        w = compact_block_weights(blk)
+        if trainable:
+            for g in (blk.attn.gate, blk.mlp.gate):
+                if not bool(((g == 0) | (g == 1)).all()):
+                    raise ValueError("shrink.compact(trainable=True) needs 0/1 gates (imp_rank masks); real-valued gates are "
+                                     "folded into the weights for inference only")
+        heads = id(blk) not in keep_heads
+        w = compact_block_weights(blk, heads=heads)
+        dev = w["qkv_w"].device
+        blk._compact_version = getattr(blk, "_compact_version", 0) + 1      # Block.block_params' cache key (never id())
         blk._compact = dict(num_heads=w["num_heads"], qkv_b=w["qkv_b"], fc1_b=w["fc1_b"],
                             qkv_w16=ops.cast_bf16(w["qkv_w"], None), proj_w16=ops.cast_bf16(w["proj_w"], None),
                             fc1_w16=ops.cast_bf16(w["fc1_w"], None), fc2_w16=ops.cast_bf16(w["fc2_w"], None),
-                            kept_heads=w["kept_heads"], kept_neurons=w["kept_neurons"])
+                            kept_heads=w["kept_heads"], kept_neurons=w["kept_neurons"], trainable=bool(trainable),
+                            heads_compacted=heads,
+                            heads_idx=torch.as_tensor(w["kept_heads"], dtype=torch.long, device=dev),
+                            neurons_idx=w["kept_neurons"].to(dev))
         report.append((len(w["kept_heads"]), w["num_heads"], len(w["kept_neurons"]), w["fc1_w"].shape[0]))
     return report
+
+
+@torch.no_grad()
+def refresh_compact(blk):
+    """Re-gather a trainable compacted block's 16-bit weights and fp32 biases from the masters' current values (the fused
+    optimizer rewrites the masters and their bf16 copies in place every step).  Gates are 0/1: nothing to fold."""
+    from .de_vit import _w16
+    c = blk._compact
+    hi, ni = c["heads_idx"], c["neurons_idx"]
+    nh, nn_ = hi.numel(), ni.numel()
+    attn, mlp = blk.attn, blk.mlp
+    D, H = attn.qkv.weight.shape[1], attn.num_heads
+    Hr, hd = c["num_heads"], 64
+    q16, p16, f1, f2 = _w16(attn.qkv), _w16(attn.proj), _w16(mlp.fc1), _w16(mlp.fc2)
+    c["qkv_w16"].view(3, Hr, hd, D)[:, :nh].copy_(q16.view(3, H, hd, D).index_select(1, hi))
+    c["proj_w16"].view(D, Hr, hd)[:, :nh].copy_(p16.view(D, H, hd).index_select(1, hi))
+    c["fc1_w16"][:nn_].copy_(f1.index_select(0, ni))
+    c["fc2_w16"][:, :nn_].copy_(f2.index_select(1, ni))
+    c["qkv_b"].view(3, Hr, hd)[:, :nh].copy_(attn.qkv.bias.detach().view(3, H, hd).index_select(1, hi))
+    c["fc1_b"][:nn_].copy_(mlp.fc1.bias.detach().index_select(0, ni))
+
+
+def attach_training(blk, bp, c):
+    """Make a compacted BlockParams trainable: compact-shaped gradient slots where the GEMM weights stand, the masters as the
+    block's parameters, and the scatter of the slots into the masters' gradients after the block's backward."""
+    attn, mlp = blk.attn, blk.mlp
+    dev = c["qkv_w16"].device
+    D, H, Hr, hd = attn.qkv.weight.shape[1], attn.num_heads, c["num_heads"], 64
+    Nr = c["fc1_w16"].shape[0]
+    hi, ni = c["heads_idx"], c["neurons_idx"]
+    nh, nn_ = hi.numel(), ni.numel()
+    slots = c.get("slots")
+    if slots is None:
+        slots = c["slots"] = dict(qkv_w=ops.GradSlot((3 * Hr * hd, D), dev), qkv_b=ops.GradSlot((3 * Hr * hd,), dev),
+                                  proj_w=ops.GradSlot((D, Hr * hd), dev), fc1_w=ops.GradSlot((Nr, D), dev),
+                                  fc1_b=ops.GradSlot((Nr,), dev), fc2_w=ops.GradSlot((D, Nr), dev))
+    bp.qkv_w, bp.proj_w, bp.fc1_w, bp.fc2_w = slots["qkv_w"], slots["proj_w"], slots["fc1_w"], slots["fc2_w"]
+    bias_slots = (slots["qkv_b"], slots["fc1_b"])
+    # the compact biases are plain fp32 tensors read by the forward; their gradients go to slots
+    qkv_b_val, fc1_b_val = c["qkv_b"], c["fc1_b"]
+    bp.qkv_b, bp.fc1_b = _BiasWithSlot(qkv_b_val, bias_slots[0]), _BiasWithSlot(fc1_b_val, bias_slots[1])
+    bp.masters = [blk.norm1.weight, blk.norm1.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight, attn.proj.bias,
+                  blk.norm2.weight, blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias]
+
+    def finish():
+        g = ops.grad_buf
+        with torch.no_grad():
+            if slots["qkv_w"].grad is not None:
+                g(attn.qkv.weight).view(3, H, hd, D).index_add_(1, hi, slots["qkv_w"].grad.view(3, Hr, hd, D)[:, :nh])
+                g(attn.qkv.bias).view(3, H, hd).index_add_(1, hi, slots["qkv_b"].grad.view(3, Hr, hd)[:, :nh])
+                g(attn.proj.weight).view(D, H, hd).index_add_(1, hi, slots["proj_w"].grad.view(D, Hr, hd)[:, :nh])
+                g(mlp.fc1.weight).index_add_(0, ni, slots["fc1_w"].grad[:nn_])
+                g(mlp.fc1.bias).index_add_(0, ni, slots["fc1_b"].grad[:nn_])
+                g(mlp.fc2.weight).index_add_(1, ni, slots["fc2_w"].grad[:, :nn_])
+                for s_ in slots.values():
+                    s_.grad.zero_()
+    bp.finish = finish
+
+
+class _BiasWithSlot:
+    """A compact fp32 bias as the kernels read it (data_ptr) whose gradient accumulates in a GradSlot."""
+    __slots__ = ("value", "slot")
+
+    def __init__(self, value, slot):
+        self.value, self.slot = value, slot
+
+    def data_ptr(self):
+        return self.value.data_ptr()
+
+    shape = property(lambda self: self.value.shape)
+    device = property(lambda self: self.value.device)
+    requires_grad = False
+
+    @property
+    def grad(self):
+        return self.slot.grad
+
+    @grad.setter
+    def grad(self, v):
+        self.slot.grad = v
 
 
 def uncompact(model):
     for blk in _blocks(model):
         blk._compact = None
+        blk._compact_version = getattr(blk, "_compact_version", 0) + 1
 
 
 def _blocks(model):

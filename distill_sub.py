@@ -251,7 +251,12 @@ def main(args):
                                 ema_decay=args.model_ema_decay if args.model_ema else None,
                                 no_decay=optim.no_decay_names(model))       # timm's two parameter groups
     loss_scaler, lr_scheduler = StepRunner(reducer), CosineEpochs(optimizer, args)
-    base = losses.SoftTargetCrossEntropy() if mixup_fn is not None else torch.nn.CrossEntropyLoss()
+    if mixup_fn is not None:                 # distill_sub.py:345-352: smoothing is handled by the mixup label transform
+        base = losses.SoftTargetCrossEntropy()
+    elif args.smoothing:
+        base = losses.LabelSmoothingCrossEntropy(smoothing=args.smoothing)
+    else:
+        base = torch.nn.CrossEntropyLoss()
     criterion = losses.DistillLoss(base, args.distillation_type, args.distillation_alpha, args.distillation_tau)
     n_parameters = sum(p_.numel() for p_ in model.parameters() if p_.requires_grad)
 

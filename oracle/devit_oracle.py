@@ -181,9 +181,25 @@ def soft_target_ce(logits, soft_targets):
     return torch.sum(-soft_targets * F.log_softmax(logits, dim=-1), dim=-1).mean()
 
 
-def distill_cls_loss(logits, logits_kd, teacher_logits, soft_targets, kind="hard", alpha=0.5, tau=1.0):
-    """utils/losses.py:135-177 (DistillLoss with a SoftTargetCrossEntropy base criterion)."""
-    base = soft_target_ce(logits, soft_targets)                               # :171
+def label_smoothing_ce(x, target, smoothing=0.1):
+    """utils/losses.py:10-34 (LabelSmoothingCrossEntropy): int64 labels."""
+    log_prob = F.log_softmax(x, dim=-1)                                        # :23
+    nll = -log_prob.gather(dim=-1, index=target.unsqueeze(1)).squeeze(1)       # :24-25
+    smooth = -log_prob.mean(dim=-1)                                            # :26
+    return ((1.0 - smoothing) * nll + smoothing * smooth).mean()               # :27,31
+
+
+def distill_cls_loss(logits, logits_kd, teacher_logits, soft_targets, kind="hard", alpha=0.5, tau=1.0, base="soft",
+                     smoothing=0.1):
+    """utils/losses.py:135-177 (DistillLoss).  base: the criterion distill_sub.py:345-352 selected -- "soft"
+    (SoftTargetCrossEntropy on [B, C] targets), "ls" (LabelSmoothingCrossEntropy(smoothing)) or "ce" (nn.CrossEntropyLoss),
+    the last two on int64 labels passed as `soft_targets`."""
+    if base == "soft":
+        base = soft_target_ce(logits, soft_targets)                           # :171
+    elif base == "ls":
+        base = label_smoothing_ce(logits, soft_targets, smoothing)
+    else:
+        base = F.cross_entropy(logits, soft_targets)
     if kind == "none":
         return base
     if kind == "hard":

@@ -405,6 +405,18 @@ def main():
         g = torch.autograd.grad(l, [lo, lk])
         res.update({f"{kind}_loss": l, f"{kind}_dlo": g[0], f"{kind}_dlk": g[1]})
     save("loss_cls", soft_targets=soft, **res)
+    # DistillLoss on hard (int64) labels with the two base criteria distill_sub.py:345-352 picks when mixup is off:
+    # LabelSmoothingCrossEntropy(smoothing) (utils/losses.py:10-34) and nn.CrossEntropyLoss
+    yl = torch.from_numpy(y1)
+    res = {}
+    for bname, base_h in (("ls", ref_losses.LabelSmoothingCrossEntropy(smoothing=0.1)), ("ce", nn.CrossEntropyLoss())):
+        for kind in ("none", "hard", "soft"):
+            crit = ref_losses.DistillLoss(base_h, kind, 0.5, 1.0 if kind != "soft" else 3.0)
+            l = crit((lo, lk), lt, yl)
+            g = torch.autograd.grad(l, [lo, lk], allow_unused=True)
+            res.update({f"{bname}_{kind}_loss": l, f"{bname}_{kind}_dlo": g[0],
+                        f"{bname}_{kind}_dlk": g[1] if g[1] is not None else torch.zeros_like(lk)})
+    save("loss_cls_hardlabels", labels=yl, **res)
 
     tf = torch.from_numpy(det_array("tf", (2, 198, 3, 12, 64), std=0.25)).permute(2, 0, 3, 1, 4)[1]
     sf = torch.from_numpy(det_array("sf", (2, 198, 3, 6, 64), std=0.25)).permute(2, 0, 3, 1, 4)[1]

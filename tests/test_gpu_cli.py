@@ -29,6 +29,38 @@ def test_distill_sub_cli(tmp_path):
     assert line["train_loss"] == line["train_loss"] and line["n_parameters"] == 21685682   # finite, C = 25
 
 
+@pytest.mark.parametrize("extra,expect", [([], "SoftTargetCrossEntropy"),
+                                          (["--mixup", "0", "--cutmix", "0"], "LabelSmoothingCrossEntropy"),
+                                          (["--mixup", "0", "--cutmix", "0", "--smoothing", "0"], "CrossEntropyLoss")])
+def test_distill_sub_base_criterion_selection(tmp_path, monkeypatch, extra, expect):
+    """distill_sub.py:345-352: SoftTargetCrossEntropy with mixup, LabelSmoothingCrossEntropy(--smoothing) without it,
+    nn.CrossEntropyLoss with neither -- and the step runs with each."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import json
+    import distill_sub
+    from devit_amd import losses
+    seen = []
+    real = losses.DistillLoss
+
+    class Rec(real):
+        def __init__(self, base, *a, **k):
+            seen.append(base)
+            super().__init__(base, *a, **k)
+    monkeypatch.setattr(losses, "DistillLoss", Rec)
+    parser = argparse.ArgumentParser(parents=[distill_sub.get_args_parser()])
+    args = parser.parse_args(["--synthetic", "2", "--batch-size", "4", "--epochs", "1", "--model", "dedeit",
+                              "--teacher-model", "deit_base_distilled_patch16_224", "--dataset", "cifar100",
+                              "--num_division", "4", "--output_dir", str(tmp_path), "--warmup-epochs", "0"] + extra)
+    distill_sub.main(args)
+    assert type(seen[0]).__name__ == expect
+    if expect == "LabelSmoothingCrossEntropy":
+        assert seen[0].smoothing == 0.1
+    line = json.loads(open(os.path.join(args.output_dir, "sub-dataset0", "log.txt")).read().splitlines()[-1])
+    assert line["train_loss"] == line["train_loss"]
+
+
 def test_distill_sub_resume(tmp_path):
     """--resume (distill_sub.py:372-388): model, optimizer moments, EMA, step count and schedule come back from
     checkpoint_temp.pth and training continues at the next epoch."""

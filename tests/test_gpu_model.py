@@ -137,6 +137,19 @@ def test_losses_vs_golden(golden, dev):
         d = torch.autograd.grad(l, [lo, lk])
         assert abs(float(l) - float(g[f"{kind}_loss"])) < 1e-5 * abs(float(g[f"{kind}_loss"]))   # fp32 kernel
         assert chk(rel(d[0], g[f"{kind}_dlo"]), 1e-5) and chk(rel(d[1], g[f"{kind}_dlk"]), 1e-5)
+    # hard labels with the two base criteria distill_sub.py:345-352 picks when mixup is off
+    g = golden("loss_cls_hardlabels")
+    y = torch.from_numpy(g["labels"]).to(dev)
+    for bname, base in (("ls", devit_amd.LabelSmoothingCrossEntropy(smoothing=0.1)), ("ce", torch.nn.CrossEntropyLoss())):
+        for kind, tau in (("none", 1.0), ("hard", 1.0), ("soft", 3.0)):
+            l = devit_amd.DistillLoss(base, kind, 0.5, tau)((lo, lk), lt, y)
+            d = torch.autograd.grad(l, [lo, lk], allow_unused=True)
+            assert abs(float(l) - float(g[f"{bname}_{kind}_loss"])) < 1e-5 * abs(float(g[f"{bname}_{kind}_loss"])), (bname, kind)
+            assert chk(rel(d[0], g[f"{bname}_{kind}_dlo"]), 1e-5)
+            if kind != "none":
+                assert chk(rel(d[1], g[f"{bname}_{kind}_dlk"]), 1e-5)
+    with pytest.raises(ValueError):       # the reference's LabelSmoothingCrossEntropy gathers by int labels (utils/losses.py:23)
+        devit_amd.DistillLoss(devit_amd.LabelSmoothingCrossEntropy(0.1), "hard", 0.5, 1.0)((lo, lk), lt, soft)
     g = golden("loss_relation")
     tf = torch.from_numpy(det_array("tf", (2, 198, 3, 12, 64), std=0.25)).to(dev).permute(2, 0, 3, 1, 4)[1]
     sf = torch.from_numpy(det_array("sf", (2, 198, 3, 6, 64), std=0.25)).to(dev).permute(2, 0, 3, 1, 4)[1]
@@ -326,7 +339,146 @@ def test_compacted_model_equals_masked_model(models, dev):
         s.train()
 
 
+def test_training_through_compacted_blocks(golden, models, dev):
+    """distill_sub.py:384-401 ranks one batch, sets the gates and then TRAINS the gated student; core/imp_rank.py:65-71,
+    147-153 only mask, so the reference pays the dense model's FLOPs there.  shrink.compact(model, trainable=True) trains
+    through the compacted blocks: one DEKD step (bs 8, recorded DropPath masks, 0.3 / 0.3 gates) against the masked HIP
+    path and against the oracle with the same gates -- losses, every parameter's gradient norm, exact zeros on the masked
+    units, and an optimizer step that moves the compact weights."""
+    from devit_amd import engine, shrink
+    s, t, st_s, st_t = models
+    g = golden("step_bs8")
+    img_c = torch.from_numpy(det_array("img8", (8, 3, 224, 224)))
+    img = img_c.to(dev)
+    soft_c = torch.from_numpy(g["soft_targets"])
+    soft = soft_c.to(dev)
+    dps_c = torch.from_numpy(g["dp_scales"])
+    dps = [(dps_c[i, 0].contiguous().to(dev), dps_c[i, 1].contiguous().to(dev)) for i in range(12)]
+    gen = torch.Generator().manual_seed(17)
+    head_gates, neuron_gates = [], []
+    for i in range(12):
+        hm, nm = torch.ones(6), torch.ones(1536)
+        hm[torch.randperm(6, generator=gen)[:2]] = 0              # int(6 * 0.7) = 4 heads kept
+        nm[torch.randperm(1536, generator=gen)[:461]] = 0         # int(1536 * 0.7) = 1075 neurons kept
+        head_gates.append(hm)
+        neuron_gates.append(nm)
+
+    def step():
+        for p in s.parameters():
+            p.grad = None
+        out = engine.distill_forward(s, t, img, soft, gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0, dp_scales=dps)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return ({k: float(out[k]) for k in ("loss", "cls_loss", "q_loss", "k_loss", "v_loss")},
+                {n: p.grad.detach().clone() for n, p in s.named_parameters()})
+    s.train()
+    try:
+        for blk, hm, nm in zip(s.blocks, head_gates, neuron_gates):
+            blk.attn.gate, blk.mlp.gate = hm.clone(), nm.clone()
+        lm, gm = step()                                            # masked: dense FLOPs
+        rep = shrink.compact(s, trainable=True)
+        assert [r[1] for r in rep] == [4] * 5 + [6] + [4] * 6      # block 5 feeds the relation loss: all heads stay
+        assert all(r[3] == 1152 for r in rep)
+        lc, gc = step()                                            # compacted
+        ref_state = {k: v.clone().requires_grad_(True) for k, v in st_s.items()}
+        ref = O.distill_step(ref_state, GS, st_t, GT, img_c, soft_c, dp_scales=dps_c, head_gates=head_gates,
+                             neuron_gates=neuron_gates)
+        for k in lm:
+            assert chk(abs(lc[k] - lm[k]) / abs(lm[k]), 2e-3), (k, lc[k], lm[k])            # same bf16 kernels, fewer zero terms
+            assert chk(abs(lc[k] - float(ref[k])) / abs(float(ref[k])), 2e-3), (k, lc[k], float(ref[k]))
+        ref["loss"].backward()
+        names = list(gm)
+        nm_ = torch.stack([gm[n].norm() for n in names]).cpu()
+        nc_ = torch.stack([gc[n].norm() for n in names]).cpu()
+        bad = (nc_ - nm_).abs() > 1e-2 * nm_ + 1e-3 * nm_.max()
+        chk(float(((nc_ - nm_).abs() / (nm_ + 1e-3 * nm_.max())).max()), 1e-2)
+        assert not bool(bad.any()), [(n, float(a), float(b)) for n, a, b, f in zip(names, nc_, nm_, bad) if f][:8]
+        for i, (hm, nmk) in enumerate(zip(head_gates, neuron_gates)):
+            dead_n = (nmk == 0).to(dev)
+            for gsel in (gm, gc):
+                assert float(gsel[f"blocks.{i}.mlp.fc1.weight"][dead_n].abs().max()) == 0.0       # masked neurons: exact zeros
+                assert float(gsel[f"blocks.{i}.mlp.fc1.bias"][dead_n].abs().max()) == 0.0
+                assert float(gsel[f"blocks.{i}.mlp.fc2.weight"][:, dead_n].abs().max()) == 0.0
+                dead_h = (hm == 0).to(dev)
+                pw = gsel[f"blocks.{i}.attn.proj.weight"].view(384, 6, 64)[:, dead_h]
+                assert float(pw.abs().max()) == 0.0
+                qw = gsel[f"blocks.{i}.attn.qkv.weight"].view(3, 6, 64, 384)[:, dead_h]
+                assert (float(qw.abs().max()) == 0.0) == (i != 5)       # the relation loss reaches the masked heads of block 5
+        # every gradient norm against the oracle's (fp32 CPU, same gates)
+        nr_ = torch.stack([ref_state[n].grad.norm() for n in names])
+        chk(float(((nc_ - nr_).abs() / (nr_ + 1e-3 * nr_.max())).max()), 1e-2)
+        bad = (nc_ - nr_).abs() > 1e-2 * nr_ + 1e-3 * nr_.max()
+        assert not bool(bad.any()), [(n, float(a), float(b)) for n, a, b, f in zip(names, nc_, nr_, bad) if f][:8]
+        # one optimizer step moves the masters; the next forward re-gathers the compact weights from them
+        before = s.blocks[2]._compact["fc1_w16"].clone()
+        with torch.no_grad():
+            for n, p in s.named_parameters():
+                p.add_(gc[n], alpha=-1.0)
+        for p in s.parameters():
+            p.grad = None
+        out = engine.distill_forward(s, t, img, soft, dp_scales=dps)
+        assert not torch.equal(s.blocks[2]._compact["fc1_w16"], before)
+        assert float(out["loss"]) == float(out["loss"])
+        with torch.no_grad():
+            for n, p in s.named_parameters():
+                p.add_(gc[n], alpha=1.0)
+    finally:
+        shrink.uncompact(s)
+        for blk in s.blocks:
+            blk.attn.gate, blk.mlp.gate = torch.ones(6), torch.ones(1536)
+        for p in s.parameters():
+            p.grad = None
+        s.train()
+
+
 # ------------------------------------------------------------------------------------------ non-distilled geometry
+def test_gate_reassignment_invalidates_block_cache(models, dev):
+    """The reference's shrink pattern (core/imp_rank.py:65-79): forward with mask A, `m.gate = ones`, `m.gate = mask B`,
+    forward.  The cached BlockParams must follow every assignment (CPython hands a freed tensor's id to the next one, so
+    the cache key is a version counter, never id()), and an in-place edit of the gate tensor too."""
+    s, _, _, _ = models
+    s.eval()
+    img = torch.from_numpy(det_array("img8", (8, 3, 224, 224)))[:2].to(dev)
+    blk = s.blocks[3]
+    H, Hd = blk.attn.num_heads, blk.mlp.hidden_features
+
+    def run():
+        with torch.no_grad():
+            return s(img).clone()
+
+    def fresh():
+        for b in s.blocks:
+            b.__dict__.pop("_bp_cache", None)
+        return run()
+    dense = run()
+    mask_a, mask_b = torch.ones(Hd), torch.ones(Hd)
+    mask_a[: Hd // 2] = 0
+    mask_b[Hd // 3:] = 0
+    try:
+        blk.mlp.gate = mask_a
+        out_a = run()
+        blk.mlp.gate = torch.ones(Hd)
+        blk.mlp.gate = mask_b.clone()
+        out_b = run()
+        assert not torch.equal(out_a, out_b) and not torch.equal(out_b, dense)
+        assert torch.equal(out_b, fresh())
+        blk.mlp.gate[: Hd // 3] = 0            # in place, no assignment: everything masked now
+        out_c = run()
+        assert not torch.equal(out_c, out_b) and torch.equal(out_c, fresh())
+        hm = torch.ones(H)
+        hm[0] = 0
+        blk.attn.gate = hm
+        out_d = run()
+        blk.attn.gate = torch.ones(H)
+        blk.attn.gate = torch.ones(H)
+        assert not torch.equal(out_d, out_c)
+    finally:
+        blk.mlp.gate = torch.ones(Hd)
+        blk.attn.gate = torch.ones(H)
+    assert torch.equal(run(), dense)
+    s.train()
+
+
 def test_nondistilled_devit_vs_oracle(dev):
     """`devit` (one class token, 197 token rows per image, tensor output in both modes; models/de_vit.py:495-513) at a
     ragged batch (3 images -> 591 rows, padded to 768): eval logits and a full backward against the CPU oracle's

@@ -110,6 +110,21 @@ def test_cls_loss(golden):
         close(l, g[f"{kind}_loss"]); close(d[0], g[f"{kind}_dlo"]); close(d[1], g[f"{kind}_dlk"])
 
 
+def test_cls_loss_hard_labels(golden):
+    """DistillLoss with the base criteria of distill_sub.py:345-352 for mixup off: LabelSmoothingCrossEntropy(0.1), CrossEntropyLoss."""
+    g = golden("loss_cls_hardlabels")
+    lo = torch.from_numpy(det_array("lo", (8, C), std=1.5)).requires_grad_(True)
+    lk = torch.from_numpy(det_array("lk", (8, C), std=1.5)).requires_grad_(True)
+    lt = torch.from_numpy(det_array("lt", (8, C), std=2.0))
+    y = torch.from_numpy(g["labels"])
+    for base in ("ls", "ce"):
+        for kind, tau in (("none", 1.0), ("hard", 1.0), ("soft", 3.0)):
+            l = O.distill_cls_loss(lo, lk, lt, y, kind, 0.5, tau, base=base, smoothing=0.1)
+            d = torch.autograd.grad(l, [lo, lk], allow_unused=True)
+            close(l, g[f"{base}_{kind}_loss"]); close(d[0], g[f"{base}_{kind}_dlo"])
+            close(d[1] if d[1] is not None else torch.zeros_like(lk), g[f"{base}_{kind}_dlk"])
+
+
 def test_relation_loss(golden):
     g = golden("loss_relation")
     tf = torch.from_numpy(det_array("tf", (2, 198, 3, 12, 64), std=0.25)).permute(2, 0, 3, 1, 4)[1]

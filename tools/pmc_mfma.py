@@ -34,7 +34,9 @@ def main():
     assert dom, "no gemm_kernel<.., A_KM=false, B_KM=false, ..> dispatch found: the kernel-name pattern is stale"
     busy = sum(tot[k]["SQ_VALU_MFMA_BUSY_CYCLES"] for k in dom)
     act = sum(tot[k]["GRBM_GUI_ACTIVE"] for k in dom) / 8.0 * 1024.0
-    res = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                   # kernel_sources_hash(): which kernel sources this summary was taken on
+    res = {"kernel_sources_hash": bench.kernel_sources_hash(), "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
                      "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace over bench.py --steps 2 --warmup 1 "
                      "--teacher-lookahead 0 (one launch at a time)",
            "dominant_template": "gemm_kernel<*, A_row, B_row, *>", "mfma_busy": round(busy / max(act, 1.0), 4),

@@ -38,7 +38,9 @@ def main():
     n = sum(rows[k]["launches"] for k in dom)
     fetch = sum(rows[k]["fetch_bytes_per_launch"] * rows[k]["launches"] for k in dom) / max(n, 1)
     write = sum(rows[k]["write_bytes_per_launch"] * rows[k]["launches"] for k in dom) / max(n, 1)
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                   # kernel_sources_hash(): which kernel sources this summary was taken on
+    res = {"kernel_sources_hash": bench.kernel_sources_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 "
                      "--teacher-lookahead 0; FETCH_SIZE x2 (gfx950 128-B requests counted as 64 B); Infinity-Cache hits included",
            "dominant_template": "gemm_kernel<*, A_row, B_row, *>", "launches": n,
            "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
