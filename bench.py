@@ -51,6 +51,11 @@ def parse():
                          "(same kernels; teacher logits 1.1e-3 instead of 6.8e-3 from the fp32 reference -- around, not inside, the "
                          "1e-3 bar -- and the step 1.4 %% slower, same-box A/B; reported as `teacher_dtype`)")
     ap.add_argument("--classes", type=int, default=0, help="override the class count (default 25 at N=1, 250 at N>1)")
+    ap.add_argument("--shrink", type=float, default=0.0,
+                    help="gate the student like distill_sub.py --neuron_shrinking --head_shrinking at this sparsity (random 0/1 masks: "
+                         "int(6 (1 - r)) heads, int(1536 (1 - r)) neurons kept per block) and train it; never the headline value")
+    ap.add_argument("--shrink-mode", default="compact", choices=["compact", "masked"],
+                    help="compact: train through the compacted blocks (shrink.compact(trainable=True)); masked: as the reference, dense FLOPs")
     ap.add_argument("--host-input", action="store_true",
                     help="PCIe-inclusive variant (DESIGN.md section 6, never the headline value): every step's batch starts "
                          "in pinned host memory and crosses to the GPU through the training loop's prefetcher")
@@ -269,6 +274,19 @@ def main():
     flat = ddp.FlatParams(student)
     ddp.broadcast_parameters(flat)          # before the bf16 GEMM copies are cast from the masters
     flat.attach_bf16(student)
+    shrink_info = None
+    if args.shrink > 0:
+        from devit_amd import shrink
+        gen = torch.Generator().manual_seed(7)
+        for blk in student.blocks:
+            hm, nm = torch.ones(6), torch.ones(1536)
+            hm[torch.randperm(6, generator=gen)[: 6 - int(6 * (1 - args.shrink))]] = 0
+            nm[torch.randperm(1536, generator=gen)[: 1536 - int(1536 * (1 - args.shrink))]] = 0
+            blk.attn.gate, blk.mlp.gate = hm, nm
+        if args.shrink_mode == "compact":
+            shrink.compact(student, trainable=True)
+        shrink_info = {"ratio": args.shrink, "mode": args.shrink_mode,
+                       "student_forward_gflop_per_img": round(shrink.compacted_gflops(student, num_classes=C), 3)}
     reducer = ddp.BucketedGradReducer(flat).attach(student)
     opt = optim.FlatAdamW(flat, lr=5e-4 * B * world / 512.0, weight_decay=0.0, max_norm=1.0, ema_decay=0.99996)
     criterion = losses.DistillLoss(losses.SoftTargetCrossEntropy(), "hard", 0.5, 1.0)
@@ -454,7 +472,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "teacher_dtype": args.teacher_precision, "data": "synthetic, pinned host batches through PCIe every step" if args.host_input else "synthetic",
             "config": {"workload": f"distill_sub step dedeit<-deit_base_distilled_patch16_224, num_division=4 "
                                    f"(C={C}), bs={B}/GPU, 224x224, hard distillation, drop_path 0.1, AdamW+EMA",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(loss_value, 5)},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(loss_value, 5),
+                       "shrink": shrink_info},
             "allreduce_ms": exchange["allreduce_ms"] if exchange else None,
             "overlap_frac": exchange["overlap_frac"] if exchange else None, "exchange": exchange,
             "roofline": roof, "cpu_baseline": cpu})

@@ -161,9 +161,10 @@ class Block(nn.Module):
                     a.gate_key(), m_.gate_key(), w16_ptr(a.qkv), w16_ptr(a.proj), w16_ptr(m_.fc1), w16_ptr(m_.fc2),
                     a.qkv.weight._version, a.proj.weight._version, m_.fc1.weight._version, m_.fc2.weight._version,
                     a.qkv.weight.data_ptr(), a.proj.weight.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc2.weight.data_ptr())
-        if c is not None and c.get("trainable") and self.training:
+        if c is not None and c.get("trainable") and (self.training or c.get("stale_after_training")):
             from . import shrink         # the optimizer rewrote the masters (and their bf16 copies) since the last forward
             shrink.refresh_compact(self)
+            c["stale_after_training"] = self.training     # the first eval forward after training re-gathers once more
         cached = getattr(self, "_bp_cache", None)
         if cached is not None and cached[0] == key():
             return cached[1]
@@ -282,7 +283,6 @@ def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=Non
         dp_scales = draw_dp_scales(bps, B, x.device, training)
     nb = len(blocks)
     lean = lean_tokens if (lean_tokens and nb >= 2 and precision != "f32" and not want_att and not want_enc and
-                           not bps[-1].compacted and
                            (not want_qkv or (qkv_pad_layers is not None and nb - 1 not in qkv_pad_layers))) else 0
     cfg = ops.EncoderCfg(bps, training, dp_scales, want_qkv, want_att, want_enc, exact_gelu=exact_gelu,
                          grad_ready=grad_ready, qkv_pad_layers=qkv_pad_layers, lean_tokens=lean)

@@ -381,6 +381,8 @@ def _tail_forward(x, bp, dp, cfg, need_grad, ntok):
     """x: fp32 [B, N, D] contiguous (output of the block before the last).  Returns (x2_tok fp32 [B, ntok, D], saved)."""
     B, N, D = x.shape
     M, T, H, dev = B * N, B * ntok, bp.num_heads, x.device
+    Da = H * 64                           # attention width (< D when heads were compacted away, shrink.compact)
+    qkv_b = getattr(bp.qkv_b, "value", bp.qkv_b)
     t16 = 1 if bp.qkv_w16.dtype == F16 else 0
     dt = F16 if t16 else BF16
     if t16 and need_grad:
@@ -390,16 +392,16 @@ def _tail_forward(x, bp, dp, cfg, need_grad, ntok):
     mean1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     rstd1 = torch.empty(M, dtype=F32, device=dev) if need_grad else None
     layernorm_fwd(x2, M, D, bp.n1w, bp.n1b, cfg.eps, y_bf16=ln1, mean=mean1, rstd=rstd1, dtype16=t16)
-    kv = rows_alloc(M, 2 * D, dt, dev)                                   # (K | V) of every row
-    linear_fwd(ln1, bp.qkv_w16[D:], bp.qkv_b[D:], M, out=kv, dtype16=t16)
+    kv = rows_alloc(M, 2 * Da, dt, dev)                                  # (K | V) of every row
+    linear_fwd(ln1, bp.qkv_w16[Da:], qkv_b[Da:], M, out=kv, dtype16=t16)
     ln1_tok = _gather_tok(ln1, B, N, ntok, D, dt, dev)
-    q_tok = rows_alloc(T, D, dt, dev)                                    # Q of the token rows
-    linear_fwd(ln1_tok, bp.qkv_w16[:D], bp.qkv_b[:D], T, out=q_tok, dtype16=t16)
-    attn_o = rows_alloc(T, D, dt, dev)
+    q_tok = rows_alloc(T, Da, dt, dev)                                   # Q of the token rows
+    linear_fwd(ln1_tok, bp.qkv_w16[:Da], qkv_b[:Da], T, out=q_tok, dtype16=t16)
+    attn_o = rows_alloc(T, Da, dt, dev)
     lse = torch.empty((B, H, ntok), dtype=F32, device=dev) if need_grad else None
-    _bracketed("attention_fwd_rows", (M * 2 * D + 2 * T * D) * 2, lambda: call(
-        "devit_attn_fwd_rows", ptr(q_tok), D, ptr(kv), 2 * D, ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, ntok, N, H,
-        D // H, (D // H) ** -0.5, t16, stream_ptr()))
+    _bracketed("attention_fwd_rows", (M * 2 * Da + 2 * T * Da) * 2, lambda: call(
+        "devit_attn_fwd_rows", ptr(q_tok), Da, ptr(kv), 2 * Da, ptr(attn_o), ptr(lse), ptr(bp.head_gate), B, ntok, N, H,
+        64, 0.125, t16, stream_ptr()))
     x_tok = _gather_tok(x2, B, N, ntok, D, F32, dev, pad=False)
     dp1, dp2 = dp if dp is not None else (None, None)
     x1 = torch.empty((B, ntok, D), dtype=F32, device=dev)
@@ -434,6 +436,7 @@ def _tail_backward(dx, s, bp, cfg):
     B, N, D = x.shape
     M, T, H, dev = B * N, B * ntok, bp.num_heads, x.device
     Hd = bp.fc1_w.shape[0]
+    Da = H * 64
     dx = dx.contiguous()
     g2 = scale_cast(dx, s["dp2"], ntok)
     # ---- MLP branch on the token rows
@@ -449,23 +452,23 @@ def _tail_backward(dx, s, bp, cfg):
     layernorm_bwd(dln2, False, s["x1"].view(T, D), T, D, s["mean2"], s["rstd2"], bp.n2w, dx.view(T, D), dx1.view(T, D),
                   g1, s["dp1"], ntok, grad_buf(bp.n2w), grad_buf(bp.n2b), gsum=grad_buf(bp.proj_b))
     # ---- attention branch: dO on the token rows; dQ there, dK / dV on every row
-    dattn = rows_alloc(T, D, BF16, dev)
+    dattn = rows_alloc(T, Da, BF16, dev)
     linear_dgrad(g1, bp.proj_w16, T, out=dattn)
     linear_wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), None, T)
-    dqkv_tok = rows_alloc(T, 3 * D, BF16, dev)                           # (dQ | dK | dV) of the token rows
-    dkv = rows_alloc(M, 2 * D, BF16, dev)
-    _bracketed("attention_bwd_rows", (M * 4 * D + 4 * T * D) * 2, lambda: call(
-        "devit_attn_bwd_rows", ptr(s["q_tok"]), D, ptr(s["kv"]), 2 * D, ptr(s["attn_o"]), ptr(dattn), ptr(s["lse"]),
-        ptr(bp.head_gate), ptr(dqkv_tok), 3 * D, ptr(dkv), 2 * D, B, ntok, N, H, D // H, (D // H) ** -0.5, stream_ptr()))
-    dqkv_tok[:T].view(B, ntok, 3 * D)[:, :, D:].copy_(dkv[:M].view(B, N, 2 * D)[:, :ntok])
+    dqkv_tok = rows_alloc(T, 3 * Da, BF16, dev)                          # (dQ | dK | dV) of the token rows
+    dkv = rows_alloc(M, 2 * Da, BF16, dev)
+    _bracketed("attention_bwd_rows", (M * 4 * Da + 4 * T * Da) * 2, lambda: call(
+        "devit_attn_bwd_rows", ptr(s["q_tok"]), Da, ptr(s["kv"]), 2 * Da, ptr(s["attn_o"]), ptr(dattn), ptr(s["lse"]),
+        ptr(bp.head_gate), ptr(dqkv_tok), 3 * Da, ptr(dkv), 2 * Da, B, ntok, N, H, 64, 0.125, stream_ptr()))
+    dqkv_tok[:T].view(B, ntok, 3 * Da)[:, :, Da:].copy_(dkv[:M].view(B, N, 2 * Da)[:, :ntok])
     dln1 = rows_alloc(M, D, BF16, dev)
-    linear_dgrad(dkv, bp.qkv_w16[D:], M, out=dln1)
+    linear_dgrad(dkv, bp.qkv_w16[Da:], M, out=dln1)
     dln1_tok = rows_alloc(T, D, BF16, dev)
     linear_dgrad(dqkv_tok, bp.qkv_w16, T, out=dln1_tok)
     dln1[:M].view(B, N, D)[:, :ntok].copy_(dln1_tok[:T].view(B, ntok, D))
     gw, gb = grad_buf(bp.qkv_w), grad_buf(bp.qkv_b)
-    linear_wgrad(dkv, s["ln1"], gw[D:], gb[D:], M)
-    linear_wgrad(dqkv_tok[:, :D], s["ln1_tok"], gw[:D], gb[:D], T)
+    linear_wgrad(dkv, s["ln1"], gw[Da:], gb[Da:], M)
+    linear_wgrad(dqkv_tok[:, :Da], s["ln1_tok"], gw[:Da], gb[:Da], T)
     dx0 = torch.empty((B, N, D), dtype=F32, device=dev)
     layernorm_bwd(dln1, False, x.view(M, D), M, D, s["mean1"], s["rstd1"], bp.n1w, None, dx0.view(M, D), None, None, 0,
                   grad_buf(bp.n1w), grad_buf(bp.n1b))
@@ -665,8 +668,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.run = None
         nb = len(cfg.blocks)
         # lean tail (EncoderCfg.lean_tokens): the last block runs on the token rows only
-        lean = cfg.lean_tokens if (cfg.lean_tokens and nb >= 2 and not cfg.want_att and not cfg.want_enc and
-                                   not getattr(cfg.blocks[-1], "compacted", False)) else 0
+        lean = cfg.lean_tokens if (cfg.lean_tokens and nb >= 2 and not cfg.want_att and not cfg.want_enc) else 0
         nbody = nb - 1 if lean else nb
         dp_last = cfg.dp_scales[nb - 1] if cfg.dp_scales is not None else None
         ctx.tail = None
@@ -719,6 +721,7 @@ class EncoderFn(torch.autograd.Function):
             if dx is None:
                 dx = torch.zeros_like(tail["x1"])
             dx = _tail_backward(dx, tail, last, cfg)
+            last.finish_grads()
             if cfg.grad_ready is not None:
                 cfg.grad_ready(last.all_params())
             nb -= 1

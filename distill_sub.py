@@ -66,6 +66,9 @@ def get_args_parser():
     p.set_defaults(pin_mem=True); a('--world_size', default=1, type=int); a('--dist_url', default='env://')
     a('--load_shrink', action='store_true', default=False); a('--shrink_checkpoint', type=str, default='')
     a('--neuron_shrinking', action='store_true', default=False); a('--head_shrinking', action='store_true', default=False)
+    a('--no-physical-shrink', dest='physical_shrink', action='store_false', default=True,
+      help='train the gated student MASKED at the dense cost, as the reference does (default: through compacted blocks, '
+           'devit_amd.shrink.compact(trainable=True): same function and gradients, the shrunk model\'s FLOPs)')
     a('--synthetic', type=int, default=0, metavar='STEPS', help='train on STEPS random on-device batches per epoch')
     a('--teacher-precision', default='bf16', choices=['f16', 'bf16'],
       help="16-bit type of the frozen teacher's forward (f16: teacher logits 1.1e-3 instead of 6.8e-3 from fp32; step 1.4 %% slower)")
@@ -280,6 +283,10 @@ def main(args):
         if policy is not None:
             print("shrink: heads kept per block", [int(h.sum()) for h, _ in policy],
                   "neurons kept per block", [int(n.sum()) for _, n in policy])
+            if args.physical_shrink:     # train at the shrunk model's FLOPs (the reference trains the masked model at the dense cost)
+                rep = shrink.compact(model, trainable=True)
+                print("shrink: compacted for training, (heads run, neurons run) per block", [(r[1], r[3]) for r in rep],
+                      f"-> {shrink.compacted_gflops(model, num_classes=num_classes):.3f} GFLOP per image forward")
 
     # distill_sub.py:403-404: everything of this division goes under sub-dataset{start_division}/ -- where ensemble.py
     # (:228) looks for `{model-path}/sub-dataset{i}/checkpoint.pth`

@@ -304,6 +304,14 @@ def test_distill_sub_shrink_flags(tmp_path):
         if os.path.exists(os.path.join(a.output_dir, "sub-dataset0", "gates.pt")) else None
     if gates is not None:                             # written with the best checkpoint (needs acc1 > 0 on random labels)
         assert all(int(h.sum()) == 3 and int(n.sum()) == 1152 for h, n in gates)
+    # the default trains through the compacted blocks; --no-physical-shrink trains the masked model at the dense cost, as the
+    # reference does: same seed, same data, same gates -> the same epoch within bf16 noise
+    import json
+    b = parse(["--output_dir", str(tmp_path / "m"), "--shrink_checkpoint", str(tmp_path / "shrink"), "--neuron_shrinking",
+               "--head_shrinking", "--no-physical-shrink"])
+    distill_sub.main(b)
+    la, lb = (json.loads(open(os.path.join(x.output_dir, "sub-dataset0", "log.txt")).read().splitlines()[-1]) for x in (a, b))
+    assert abs(la["train_loss"] - lb["train_loss"]) < 2e-2 * abs(lb["train_loss"]), (la["train_loss"], lb["train_loss"])
     with pytest.raises(ValueError):
         distill_sub.main(parse(["--output_dir", str(tmp_path / "p"), "--neuron_shrinking"]))
     for bad in (["--opt", "sgd"], ["--sched", "step"]):
