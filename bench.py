@@ -56,6 +56,10 @@ def parse():
                          "int(6 (1 - r)) heads, int(1536 (1 - r)) neurons kept per block) and train it; never the headline value")
     ap.add_argument("--shrink-mode", default="compact", choices=["compact", "masked"],
                     help="compact: train through the compacted blocks (shrink.compact(trainable=True)); masked: as the reference, dense FLOPs")
+    ap.add_argument("--rehearse-exchange", default="none", choices=["none", "abi", "torch"],
+                    help="N = 1 only, never the headline value: send every gradient bucket through RCCL on the exchange stream "
+                         "during backward although there is one rank (abi: the C ABI's devit_comm_* communicator; torch: a "
+                         "world-size-1 torch.distributed nccl group); the reducer is told it has two ranks, so gradients are halved")
     ap.add_argument("--host-input", action="store_true",
                     help="PCIe-inclusive variant (DESIGN.md section 6, never the headline value): every step's batch starts "
                          "in pinned host memory and crosses to the GPU through the training loop's prefetcher")
@@ -287,7 +291,17 @@ def main():
             shrink.compact(student, trainable=True)
         shrink_info = {"ratio": args.shrink, "mode": args.shrink_mode,
                        "student_forward_gflop_per_img": round(shrink.compacted_gflops(student, num_classes=C), 3)}
-    reducer = ddp.BucketedGradReducer(flat).attach(student)
+    if args.rehearse_exchange != "none" and world == 1:
+        if args.rehearse_exchange == "abi":
+            reducer = ddp.BucketedGradReducer(flat, comm=ddp.RcclComm(rank=0, world=1), world=2).attach(student)
+        else:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1)
+            reducer = ddp.BucketedGradReducer(flat, world=2).attach(student)
+    else:
+        reducer = ddp.BucketedGradReducer(flat).attach(student)
+    from devit_amd import _lib as _L
+    reserved_cus = _L.load().devit_get_reserved_cus()
     opt = optim.FlatAdamW(flat, lr=5e-4 * B * world / 512.0, weight_decay=0.0, max_norm=1.0, ema_decay=0.99996)
     criterion = losses.DistillLoss(losses.SoftTargetCrossEntropy(), "hard", 0.5, 1.0)
 
@@ -373,13 +387,14 @@ def main():
 
     # ---- gradient exchange of one more step: summed bucket all-reduce time and the share of it that ran under backward
     exchange = None
-    if world > 1:
+    if reducer.world > 1:
         reducer.timing = True
         step()
         reducer.timing = False
         ar_ms, ov = reducer.timing_summary()
         t = torch.tensor([ar_ms, -ov], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                  # worst rank, like the step time: longest exchange, least overlap
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)              # worst rank, like the step time: longest exchange, least overlap
         exchange = {"allreduce_ms": round(float(t[0]), 3), "overlap_frac": round(-float(t[1]), 3),
                     "buckets": len(reducer.buckets), "bytes": flat.numel * 4,
                     "over_ranks": "max allreduce_ms, min overlap_frac"}
@@ -474,12 +489,15 @@ def main():
                                    f"(C={C}), bs={B}/GPU, 224x224, hard distillation, drop_path 0.1, AdamW+EMA",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(loss_value, 5),
                        "shrink": shrink_info},
+            "reserved_cus": reserved_cus, "reserved_cus_while_buckets_in_flight": reducer.reserve_cus if reducer.world > 1 else 0,
+            "rehearse_exchange": args.rehearse_exchange,
+            "bucket_mb": [round((e - s_) * 4 / 2 ** 20, 2) for s_, e, _, _ in reducer.buckets],
             "allreduce_ms": exchange["allreduce_ms"] if exchange else None,
             "overlap_frac": exchange["overlap_frac"] if exchange else None, "exchange": exchange,
             "roofline": roof, "cpu_baseline": cpu})
         json_out.write(line + "\n")
         json_out.flush()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "devit_last_error": (C.c_char_p, []),
     "devit_check_device": (_I, [_I]),
     "devit_gemm_bf16": (_I, [C.POINTER(Operand), C.POINTER(Operand), _I, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
+    "devit_set_reserved_cus": (_I, [_I]),
+    "devit_get_reserved_cus": (_I, []),
     "devit_layernorm_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P]),
     "devit_layernorm_bwd_workspace": (_Z, [_I, _I]),
     "devit_layernorm_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),

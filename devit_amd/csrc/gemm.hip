@@ -908,7 +908,28 @@ void gemm_kernel(const GemmArgs g) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// CUs the persistent grids leave free (devit_set_reserved_cus): -1 = not set yet, take DEVIT_RESERVE_CUS from the environment
+int g_reserved_cus = -1;
+
+int reserved_cus() {
+  if (g_reserved_cus < 0) {
+    const char* e = getenv("DEVIT_RESERVE_CUS");
+    int n = e ? atoi(e) : 0;
+    g_reserved_cus = (n >= 0 && n <= 128) ? n / 8 * 8 : 0;
+  }
+  return g_reserved_cus;
+}
+
 }  // namespace
+
+extern "C" int devit_set_reserved_cus(int n) {
+  DEVIT_CHECK(n >= 0 && n <= 128 && n % 8 == 0, DEVIT_ERR_ARG,
+              "devit_set_reserved_cus: %d is not a multiple of 8 in [0, 128] (one share per XCD)", n);
+  g_reserved_cus = n;
+  return DEVIT_OK;
+}
+
+extern "C" int devit_get_reserved_cus(void) { return reserved_cus(); }
 
 extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bop, int M, int N, int K, int batch,
                                int split_k, const devit_epilogue* ep, void* stream) {
@@ -1014,7 +1035,12 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   }
   static const int occ_env = getenv("DEVIT_GEMM_OCC") ? atoi(getenv("DEVIT_GEMM_OCC")) : 0;
   const int occ = occ_env > 0 ? occ_env : (cfg == 1 ? 2 : 1);
-  long long nwg = ((long long)cus * occ) / 8 * 8;
+  // A persistent grid holds every CU it starts on (the 256x256 workgroup owns the CU's whole LDS and register file) until
+  // its last tile: a collective's kernels launched meanwhile (RCCL on the exchange stream) wait for a GEMM to END, and once
+  // they hold CUs the next 256-workgroup grid runs a second, nearly empty round.  With `reserved` CUs left free the grid
+  // is smaller and its tiles are dealt over the workgroups that do run (devit_set_reserved_cus; 0 at world size 1).
+  const int avail = cus - reserved_cus() >= 8 ? cus - reserved_cus() : 8;
+  long long nwg = ((long long)avail * occ) / 8 * 8;
   if (nwg > (tiles + 7) / 8 * 8) nwg = (tiles + 7) / 8 * 8;
   hipStream_t s = (hipStream_t)stream;
 #define DEVIT_LAUNCH_ONE_T(BM_, BN_, WMM_, WNN_, NS_, AKM_, BKM_, KIND_, F16_)                                   \

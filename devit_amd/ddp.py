@@ -119,24 +119,54 @@ class RcclComm:
             self._comm = self._C.c_void_p()
 
 
+def _report_group(name):
+    """Which grad_ready report a parameter belongs to, in backward order: (0, 0) heads and final norm, (1, k) encoder
+    block k, (2, 0) embeddings (patch projection, class / distillation tokens, position embedding)."""
+    name = name[7:] if name.startswith("module.") else name
+    if name.startswith("blocks."):
+        return (1, int(name.split(".")[1]))
+    if name.startswith(("patch_embed", "pos_embed", "cls_token", "dist_token")):
+        return (2, 0)
+    return (0, 0)
+
+
 class BucketedGradReducer:
     """All-reduce (sum) of FlatParams.flat_grad in buckets, fired from `grad_ready` callbacks.
 
     comm: anything with `.world` and `.all_reduce(flat_f32_view, stream=)` (RcclComm, or a recording stand-in in the
     tests) -> the buckets go through it instead of torch.distributed."""
 
-    def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, process_group=None, comm=None, world=None):
+    def __init__(self, flat: FlatParams, bucket_bytes=25 << 20, process_group=None, comm=None, world=None, plan="layers"):
         self.flat, self.group, self.comm = flat, process_group, comm
         if world is not None:
             self.world = world
         else:
             self.world = comm.world if comm is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
-        # bucket boundaries on parameter boundaries, in flat (= reverse forward) order
+        # bucket boundaries on parameter boundaries, in flat (= reverse forward) order.  plan="layers" cuts where backward
+        # REPORTS (grad_ready: heads + final norm, then one encoder block at a time, then the embeddings): the first bucket
+        # is heads + norm + the last block (it leaves as soon as that block's backward is enqueued), full blocks are
+        # grouped up to bucket_bytes, and the embeddings -- whose gradients only exist when backward is over -- travel alone
+        # (1.5 MB for `dedeit`: the part of the exchange nothing can overlap).  plan="size": fixed-size cuts.
+        groups = [_report_group(n) for n in flat.names]
         self.buckets, start, last = [], 0, 0
         limit = bucket_bytes // 4
-        for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
-            end = flat.offsets[i + 1] if i + 1 < len(flat.params) else flat.numel
-            if end - start >= limit or i + 1 == len(flat.params):
+        nparams = len(flat.params)
+        first_block = next((g for g in groups if g[0] == 1), None)
+        final_block = next((g for g in reversed(groups) if g[0] == 1), None)   # block 0: its bucket cannot overlap much, keep it alone
+        for i in range(nparams):
+            end = flat.offsets[i + 1] if i + 1 < nparams else flat.numel
+            last_of_group = i + 1 == nparams or groups[i + 1] != groups[i]
+            if plan == "layers" and first_block is not None:
+                nxt = groups[i + 1] if i + 1 < nparams else None
+                cut = last_of_group and (
+                    i + 1 == nparams
+                    or groups[i] == first_block                       # heads + norm + last block: out first
+                    or nxt[0] == 2                                    # everything before the embeddings
+                    or nxt == final_block
+                    or (groups[i][0] == 1 and end - start + self._group_elems(groups, i + 1) > limit))
+            else:
+                cut = end - start >= limit or i + 1 == nparams
+            if cut:
                 self.buckets.append((start, end, last, i))        # [elem start, elem end), param index range
                 start, last = end, i + 1
         self.bucket_of = {}
@@ -145,9 +175,31 @@ class BucketedGradReducer:
                 self.bucket_of[i] = b
         self.cuda = flat.flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
+        # CUs the persistent GEMM grids leave free WHILE buckets are in flight (first bucket launched -> finish()).  A
+        # collective's workgroups hold CUs for the length of the collective; they cannot share a CU with a GEMM workgroup
+        # (LDS and registers are full), so they start when a GEMM ends and a 256-workgroup grid launched meanwhile runs a second,
+        # nearly empty round on what is left.  Measured on one GPU (profiles/r03_f_*): a 32-workgroup stand-in kernel starts
+        # within 42 us only with 32 CUs reserved (one per shader engine; 160-190 us with 0 / 8 / 16), and keeping 16 / 32 CUs
+        # free costs the step 4.3 / 5.2 % whether scoped to this window or permanent (the window is the backward, where
+        # the two-workgroups-per-CU GEMMs live).  The exchange itself is ~1 ms of an ~11 ms backward, so even a 2x slowdown
+        # of the GEMMs beside it costs less than the reservation: the default is 0.  DEVIT_RESERVE_CUS_EXCHANGE=n turns the
+        # scoped form on (what to try first if the 8-GPU curve shows backward stretching under the all-reduce);
+        # DEVIT_RESERVE_CUS=n is the library's permanent form.
+        import os
+        self.reserve_cus = int(os.environ.get("DEVIT_RESERVE_CUS_EXCHANGE", "0")) if self.cuda else 0
+        self._reserved = False
         self.timing = False          # bench.py: record events around every bucket (allreduce_ms / overlap_frac)
         self.last_timing = None
         self.reset()
+
+    def _group_elems(self, groups, i):
+        """Elements of the report group that starts at parameter i."""
+        n, j = 0, i
+        while j < len(groups) and groups[j] == groups[i]:
+            end = self.flat.offsets[j + 1] if j + 1 < len(groups) else self.flat.numel
+            n += end - self.flat.offsets[j]
+            j += 1
+        return n
 
     def reset(self):
         self.pending = [p1 - p0 + 1 for (_, _, p0, p1) in self.buckets]
@@ -182,6 +234,10 @@ class BucketedGradReducer:
             return
         s, e, _, _ = self.buckets[b]
         view = self.flat.flat_grad[s:e]
+        if self.cuda and self.reserve_cus and not self._reserved:
+            from . import _lib as L
+            L.call("devit_set_reserved_cus", self.reserve_cus)      # GEMM grids enqueued from here on leave room for the collective
+            self._reserved = True
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())          # backward kernels of this bucket are enqueued
@@ -220,6 +276,10 @@ class BucketedGradReducer:
             h.wait()
         if self.cuda and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.stream)
+        if self._reserved:
+            from . import _lib as L
+            L.call("devit_set_reserved_cus", 0)
+            self._reserved = False
         self.flat.grad_scale = 1.0 / self.world
         if average and self.world > 1:
             self.flat.flat_grad.mul_(1.0 / self.world)

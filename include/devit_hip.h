@@ -104,6 +104,12 @@ typedef struct {
 
 int devit_gemm_bf16(const devit_operand* A, const devit_operand* B, int M, int N, int K, int batch, int split_k,
                     const devit_epilogue* ep, void* stream);
+/* The GEMM grids are persistent: one (256x256 tile) or two (128x128) workgroups per CU that walk their share of the tiles.
+ * devit_set_reserved_cus(n) makes every later launch leave n CUs (a multiple of 8: one share per XCD) free for kernels of
+ * other streams -- the RCCL all-reduce of the data-parallel step (distill_sub.py:333), whose kernels could otherwise start
+ * only when a GEMM ends.  Default: the DEVIT_RESERVE_CUS environment variable, else 0.  Process-wide. */
+int devit_set_reserved_cus(int n);
+int devit_get_reserved_cus(void);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the fp32 residual stream.  Replaces nn.LayerNorm(D, eps=1e-6) at

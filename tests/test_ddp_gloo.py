@@ -122,3 +122,33 @@ def test_module_broadcast_and_gradient_mean_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def test_layer_bucket_plan():
+    """plan="layers" (default): buckets are cut where backward reports -- heads + final norm + the last block leave first, whole
+    blocks are grouped up to bucket_bytes, block 0 and the embeddings travel alone so that what no backward kernel can overlap
+    stays small (reverse-layer-order buckets launched as each bucket's gradients complete)."""
+    import devit_amd
+    m = devit_amd.create_model("dedeit", num_classes=250)
+    flat = ddp.FlatParams(m)
+    red = ddp.BucketedGradReducer(flat, world=2)
+    names = flat.names
+    spans = [(names[p0], names[p1], (e - s) * 4) for s, e, p0, p1 in red.buckets]
+    # contiguous cover of the flat buffer, in flat (= reverse forward) order
+    assert red.buckets[0][0] == 0 and red.buckets[-1][1] == flat.numel
+    assert all(a[1] == b[0] and a[3] + 1 == b[2] for a, b in zip(red.buckets, red.buckets[1:]))
+    first = names[red.buckets[0][2]:red.buckets[0][3] + 1]
+    assert first[0].startswith("head") and any(n.startswith("norm.") for n in first) and first[-1].startswith("blocks.11.")
+    assert not any(n.startswith("blocks.10.") for n in first)
+    last = names[red.buckets[-1][2]:red.buckets[-1][3] + 1]
+    assert all(n.startswith(("patch_embed", "pos_embed", "cls_token", "dist_token")) for n in last) and spans[-1][2] <= 3 << 20
+    b0 = names[red.buckets[-2][2]:red.buckets[-2][3] + 1]
+    assert all(n.startswith("blocks.0.") for n in b0)
+    assert all(sz <= (25 << 20) for _, _, sz in spans)
+    # every block sits in exactly one bucket
+    for k in range(12):
+        owners = {red.bucket_of[i] for i, n in enumerate(names) if n.startswith(f"blocks.{k}.")}
+        assert len(owners) == 1
+    # a model without encoder blocks falls back to fixed-size cuts
+    t = torch.nn.Sequential(torch.nn.Linear(24, 48), torch.nn.Linear(48, 48), torch.nn.Linear(48, 5))
+    assert len(ddp.BucketedGradReducer(ddp.FlatParams(t), bucket_bytes=4096, world=2).buckets) >= 2
