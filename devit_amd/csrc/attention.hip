@@ -8,6 +8,8 @@
 //
 // LDS images are [rows][64] bf16 (128-byte rows); 16-byte chunk c of row r is stored at chunk
 // c ^ ((r >> 1) & 7): conflict-free ds_read_b128 row fragments, 2-way ds_read_b64_tr_b16.
+#include <stdlib.h>
+
 #include "devit_common.h"
 
 namespace {
@@ -52,8 +54,14 @@ __device__ __forceinline__ void fetch_rows(RowRegs<NT>& r, const __bf16* src, si
 #pragma unroll
   for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
     const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
+    // unconditional load from a clamped row, zeroed afterwards: a load under a per-element condition makes hipcc branch
+    // around it and wait for each one in turn (one HBM round trip per iteration)
+    r.v[it] = *(const bf16x8*)(src + (size_t)min(row, N - 1) * row_stride + c * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    r.v[it] = row < N ? *(const bf16x8*)(src + (size_t)row * row_stride + c * 8) : z;
+    if ((tid + it * NT) >> 3 >= N) r.v[it] = z;
   }
 }
 template <int NT>
@@ -210,12 +218,11 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward.  Recomputes P from the saved log-sum-exp.  S and dP are computed with the KEY on the MFMA lane, so
-// their accumulators (two 16-query tiles = one 32-query block) are already the B operands of
-// dV^T += dO^T P and dK^T += Q^T dS: P never touches LDS and each wave keeps dK/dV of its own key tiles in
-// registers for the whole kernel (no cross-workgroup reduction, no atomics).  Only dS crosses LDS, once, stored
-// transposed ([key][q], 8-byte writes) and double-buffered (one barrier per query block), for
-// dQ^T = K^T dS^T.  Every gradient leaves as 8-byte (4 x bf16) stores along d.
+// Backward.  Recomputes P from the saved log-sum-exp.  S and dP are computed with the KEY on the MFMA lane, so their
+// accumulators (two 16-query tiles = one 32-query block) are already the B operands of dV^T += dO^T P and
+// dK^T += Q^T dS: P never touches LDS and each wave keeps dK / dV of its own key tiles in registers for the whole kernel
+// (no cross-workgroup reduction, no atomics).  Only dS crosses LDS, once per block, stored transposed ([key][q], 8-byte
+// writes), for dQ^T = K^T dS^T.
 // ------------------------------------------------------------------------------------------
 struct AttnBwdArgs {
   const __bf16* q;      // [B*NQ][q_rs]; query side / key side split as in AttnFwdArgs
@@ -236,9 +243,6 @@ struct AttnBwdArgs {
   float scale;
 };
 
-constexpr int DST_STRIDE = 40;                       // bf16 per dS^T row: 32 queries + pad (80-B rows)
-constexpr int DST_BYTES = KROWS * DST_STRIDE * 2;    // 17920
-
 __device__ __forceinline__ void store_grad4(__bf16* dst, const __bf16* add, f32x4 v) {
   if (add) {
     const bf16x4 e = *(const bf16x4*)add;
@@ -248,16 +252,59 @@ __device__ __forceinline__ void store_grad4(__bf16* dst, const __bf16* add, f32x
   *(bf16x4*)dst = o;
 }
 
-constexpr int BWD_WAVES = 8;
+// ------------------------------------------------------------------------------------------
+// Two workgroups per CU: 4 waves, <= 256 VGPRs, 79 KB of LDS each.  (Rounds 1-2 ran 8 waves with four [224][64] images in
+// LDS, 152 KB: one workgroup per CU, so load -> compute -> store ran strictly one after the other on every CU -- 181 us per
+// B = 256, H = 6 launch from cold HBM against 160 us for this form, profiles/r03_*_attention_bwd.txt.)  Only the K image
+// stays in LDS (the dQ product needs every key's row); V lives in registers as the row fragments of the wave's own key
+// tiles; Q and dO arrive one 32-query block at a time through a four-stage LDS ring filled by LDS-DMA up to three blocks
+// ahead (counted vmcnt); the block's Q / dO fragments are re-read from LDS per key tile because 128 accumulator + 32
+// V-fragment registers leave no room to hold them.  Two such workgroups share a CU and run out of phase: one loads or
+// stores while the other computes.  Same MFMA shapes, operand roundings and reduction order over query blocks / key steps
+// as the 8-wave kernel had, except that the head gate multiplies dP and dV in fp32 instead of a bf16 copy of dO: identical
+// for the 0/1 gates of core/imp_rank.py.
+// In-kernel stamps (tools/attn_stamps.py, -DDEVIT_ATTN_STAMP): a workgroup lives ~47 us = prologue 23 (140 KB of first-touch
+// loads at the ~3-6 B/cycle its CU's load path gives it beside the other workgroup) + main loop 22 (bound by
+// vector-instruction ISSUE, ~600 instructions per wave and block, not by MFMA or memory: halving the instruction count of
+// the softmax-gradient arithmetic took it from 26 to 22) + stores 2.
+// ------------------------------------------------------------------------------------------
+constexpr int B4_WAVES = 4;
+constexpr int B4_KT = (MAXT + 1 + B4_WAVES - 1) / B4_WAVES;      // key tiles per wave (4); tile 13 (keys 208..223) is padding
+constexpr int DST4_STRIDE = 36;                                   // bf16 per dS^T row: 32 queries + pad (72-B rows)
+constexpr int DST4_BYTES = KROWS * DST4_STRIDE * 2;               // 16128
+constexpr int QD_STAGE = 2 * 32 * HD * 2;                         // one ring stage: Q block + dO block, 8192 B
+constexpr int QD_NST = 4;                                         // ring stages: three blocks (24 KB per workgroup) in flight
+constexpr int BWD4_LDS = IMG_BYTES + QD_NST * QD_STAGE + DST4_BYTES + 2 * KROWS * 4;   // 79360
 
-__global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdArgs a) {
+// one LDS-DMA instruction (1 KiB: 8 rows x 128 B) from per-lane global addresses to LDS byte address `lds`; inline asm so
+// that hipcc's waitcnt pass does not put a vmcnt(0) in front of every later ds_read (gemm.hip, dma2_perlane)
+__device__ __forceinline__ void dma1(const void* p, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 2\n\t"
+      "global_load_lds_dwordx4 %2, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds), "v"(p)
+      : "memory", "scc");
+}
+
+// rows [r0, r0 + 32) of a strided [N][64] matrix -> a [32][64] LDS block image (swizzled like the big images, local rows);
+// wave w moves slab w (rows 8 w .. 8 w + 7); rows >= nrows repeat row nrows - 1
+__device__ __forceinline__ void dma_block(char* blk, const __bf16* src, size_t row_stride, int r0, int nrows, int wave, int lane) {
+  const int lr = wave * 8 + (lane >> 3), c = (lane & 7) ^ ((lr >> 1) & 7);
+  const __bf16* g = src + (size_t)min(r0 + lr, nrows - 1) * row_stride + c * 8;
+  dma1(g, (unsigned)(size_t)LDS_PTR(blk) + (unsigned)wave * 1024u);
+}
+
+__global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* q_img = smem;
-  char* k_img = smem + IMG_BYTES;
-  char* v_img = smem + 2 * IMG_BYTES;
-  char* do_img = smem + 3 * IMG_BYTES;
-  char* dst_buf = smem + 4 * IMG_BYTES;              // 2 x [224 keys][DST_STRIDE]
-  float* lse2 = (float*)(dst_buf + 2 * DST_BYTES);
+  char* k_img = smem;
+  char* qd = smem + IMG_BYTES;                       // QD_NST stages x {Q block [32][64], dO block [32][64]}
+  char* dst = qd + QD_NST * QD_STAGE;                // dS^T of the current block: [224 keys][DST4_STRIDE]
+  float* lse2 = (float*)(dst + DST4_BYTES);
   float* delta = lse2 + KROWS;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -266,27 +313,51 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
   const int D = a.H * HD, N = a.N, NQ = a.NQ;
   const size_t rs = (size_t)a.q_rs, krs = (size_t)a.kv_rs;
   const __bf16* qbase = a.q + (size_t)b * NQ * rs + h * HD;
+  const __bf16* kbase = a.k + (size_t)b * N * krs + h * HD;
+  const __bf16* vbase = a.v + (size_t)b * N * krs + h * HD;
+#ifdef DEVIT_ATTN_STAMP    // diagnostic build (tools/attn_stamps.py): head_gate carries a u64 stamp buffer, 8 per workgroup
+  unsigned long long* stamps = (unsigned long long*)a.head_gate + (size_t)blockIdx.x * 8;
+  const float gate = 1.0f;
+  if (tid == 0) { stamps[0] = __builtin_amdgcn_s_memrealtime(); stamps[1] = __builtin_amdgcn_s_memtime(); }
+#define ATTN_STAMP(i) do { if (tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
   const float gate = a.head_gate ? a.head_gate[h] : 1.0f;
+#define ATTN_STAMP(i) do { } while (0)
+#endif
   const __bf16* dobase = a.dout + (size_t)b * NQ * D + h * HD;
   const __bf16* obase = a.out + (size_t)b * NQ * D + h * HD;
+  const int g = lane >> 4, lc = lane & 15;
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+  const int ntile = (N + 15) >> 4;
+  const int nblk = (NQ + 31) >> 5;
 
+  // ---- prologue: K image and the first Q / dO block by LDS-DMA; V fragments of this wave's key tiles straight to registers;
+  // delta[q] = sum_d dO[q][d] O[q][d] and lse from global rows
+  dma_image<B4_WAVES>(k_img, kbase, krs, N, wave, lane);
+#pragma unroll
+  for (int pb = 0; pb < QD_NST - 1; ++pb)
+    if (pb < nblk) {
+      dma_block(qd + pb * QD_STAGE, qbase, rs, pb * 32, NQ, wave, lane);
+      dma_block(qd + pb * QD_STAGE + 32 * HD * 2, dobase, (size_t)D, pb * 32, NQ, wave, lane);
+    }
+  bf16x8 vf[B4_KT][2];
+#pragma unroll
+  for (int t = 0; t < B4_KT; ++t) {
+    const int key = min((wave + t * B4_WAVES) * 16 + lc, N - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) vf[t][kk] = *(const bf16x8*)(vbase + (size_t)key * krs + kk * 32 + g * 8);
+  }
   {
-    // Q, K, V images by LDS-DMA (issued first: they are in flight while the rest of the prologue runs); dO (scaled by the
-    // head gate), the O rows and lse go through registers because delta[q] = sum_d dO[q][d] O[q][d] needs them there
-    constexpr int NT = BWD_WAVES * 64;
-    dma_image<BWD_WAVES>(q_img, qbase, rs, NQ, wave, lane);
-    dma_image<BWD_WAVES>(k_img, a.k + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
-    dma_image<BWD_WAVES>(v_img, a.v + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
+    constexpr int NT = B4_WAVES * 64;
     RowRegs<NT> dr, orr;
-    float ls[RowRegs<NT>::ITERS];
     fetch_rows(dr, dobase, (size_t)D, NQ, tid);
     fetch_rows(orr, obase, (size_t)D, NQ, tid);
-#pragma unroll
-    for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
-      const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
-      ls[it] = (row < NQ && c == 0) ? a.lse[((size_t)b * a.H + h) * NQ + row] * 1.4426950408889634f : 0.f;
-    }
-    for (int i = tid; i < 2 * DST_BYTES / 16; i += NT) ((f32x4*)dst_buf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ATTN_STAMP(6);                                     // every prologue load is issued
+#ifdef DEVIT_ATTN_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(7);                                     // ... and has landed
+#endif
+    for (int i = tid; i < DST4_BYTES / 16; i += NT) ((f32x4*)dst)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < RowRegs<NT>::ITERS; ++it) {
       const int idx = tid + it * NT, row = idx >> 3, c = idx & 7;
@@ -297,71 +368,48 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
       dl += __shfl_xor(dl, 2, 64);
       dl += __shfl_xor(dl, 4, 64);
       if (c == 0 && row < KROWS) {
-        delta[row] = dl;
-        lse2[row] = ls[it];
+        delta[row] = dl * a.scale;                   // pre-scaled: dS = P * (dP * gate * scale - delta * scale)
+        lse2[row] = row < NQ ? a.lse[((size_t)b * a.H + h) * NQ + row] * 1.4426950408889634f : 0.f;
       }
     }
-    put_image(do_img, dr, gate, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  ATTN_STAMP(2);
 
   const float c2 = a.scale * 1.4426950408889634f;
-  const int ntile = (N + 15) >> 4;
-  const int g = lane >> 4, lc = lane & 15;
-  const int tq = (lane >> 2) & 3, tp = lane & 3;
-
-  constexpr int KT = (MAXT + BWD_WAVES - 1) / BWD_WAVES;   // key tiles per wave (2)
-  f32x4 dv[KT][4], dk[KT][4];  // [key tile of this wave][d tile]: rows d = 4g + r, col key = lc
+  const float gs = gate * a.scale;
+  f32x4 dv[B4_KT][4], dk[B4_KT][4];  // [key tile of this wave][d tile]: rows d = 4g + r, col key = lc
 #pragma unroll
-  for (int i = 0; i < KT; ++i)
+  for (int i = 0; i < B4_KT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       dv[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dk[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-  const int nblk = (NQ + 31) >> 5;
   for (int qb = 0; qb < nblk; ++qb) {
-    char* dst = dst_buf + (qb & 1) * DST_BYTES;
-    // ---- S, dP for this wave's key tiles x the block's two query tiles; dV^T, dK^T straight from registers
-    bf16x8 qf[2][2], dof[2][2];
-    float l2[2][4], dl[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q0 = qb * 32 + i * 16;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        qf[i][kk] = img_row_frag(q_img, q0, kk, lane);
-        dof[i][kk] = img_row_frag(do_img, q0, kk, lane);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        l2[i][r] = lse2[q0 + g * 4 + r];
-        dl[i][r] = delta[q0 + g * 4 + r];
-      }
+    const char* q_blk = qd + (qb & (QD_NST - 1)) * QD_STAGE;
+    const char* do_blk = q_blk + 32 * HD * 2;
+    // Q / dO of block qb + 3 into the stage block qb - 1 was read from (every wave is past that block's barriers).  Exactly
+    // two LDS-DMA instructions per wave and block: the counted wait below relies on it.
+    if (qb + QD_NST - 1 < nblk) {
+      char* nq = qd + ((qb + QD_NST - 1) & (QD_NST - 1)) * QD_STAGE;
+      dma_block(nq, qbase, rs, (qb + QD_NST - 1) * 32, NQ, wave, lane);
+      dma_block(nq + 32 * HD * 2, dobase, (size_t)D, (qb + QD_NST - 1) * 32, NQ, wave, lane);
     }
-    // A operands of the dV^T / dK^T products: dO^T and Q^T with k-slot (g, j) = query 16 (j>>2) + 4g + (j&3)
-    bf16x8 dot[4], qtt[4];
-    {
-      const int r0 = qb * 32 + g * 4 + tq, r1 = r0 + 16;
+    // ---- per key tile of this wave: S and dP against the block's two query tiles -> P, dS (registers = MFMA operands, dS^T also
+    // to LDS), then dV^T += dO^T P and dK^T += Q^T dS.  The block's Q / dO fragments are read from LDS per tile, not held
+    // across tiles: with 128 accumulator and 32 V-fragment registers there is no room for them (256 per wave at two
+    // workgroups per CU), and LDS has the bandwidth (~70 KB per wave and block).
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int ch = dt * 2 + (tp >> 1), sub = (tp & 1) * 8;
-        dot[dt] = cat8(lds_tr_read(do_img + img_off(r0, ch) + sub), lds_tr_read(do_img + img_off(r1, ch) + sub));
-        qtt[dt] = cat8(lds_tr_read(q_img + img_off(r0, ch) + sub), lds_tr_read(q_img + img_off(r1, ch) + sub));
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      const int kt = wave + t * BWD_WAVES;
+    for (int t = 0; t < B4_KT; ++t) {
+      const int kt = wave + t * B4_WAVES;
       if (kt < ntile) {
-        bf16x8 kf[2], vf[2];
+        asm volatile("" ::: "memory");                 // keep hipcc from hoisting (and keeping alive) the loop-invariant LDS reads
+        bf16x8 kf[2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          kf[kk] = img_row_frag(k_img, kt * 16, kk, lane);
-          vf[kk] = img_row_frag(v_img, kt * 16, kk, lane);
-        }
+        for (int kk = 0; kk < 2; ++kk) kf[kk] = img_row_frag(k_img, kt * 16, kk, lane);
         f32x4 pp[2], ds[2];
         const bool kok = kt * 16 + lc < N;
 #pragma unroll
@@ -369,73 +417,100 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
           f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
-            sv = mfma16(qf[i][kk], kf[kk], sv);      // S[q][key], key on the lane
-            dp = mfma16(dof[i][kk], vf[kk], dp);     // dP[q][key]
+            sv = mfma16(img_row_frag(q_blk, i * 16, kk, lane), kf[kk], sv);       // S[q][key], key on the lane
+            dp = mfma16(img_row_frag(do_blk, i * 16, kk, lane), vf[t][kk], dp);   // dP[q][key] (before the head gate)
           }
+          const f32x4 l2 = *(const f32x4*)(lse2 + qb * 32 + i * 16 + g * 4), dl = *(const f32x4*)(delta + qb * 32 + i * 16 + g * 4);
+          // The kernel is bound by vector-instruction issue (~1150 per wave and block before this form), not by MFMA or
+          // memory: four instructions per element on the interior (fma, v_exp, fma, mul), the masks only where padded keys
+          // (last key tile) or padded queries (last block) exist -- wave-uniform branch.
+          if (kt * 16 + 16 <= N && qb * 32 + i * 16 + 16 <= NQ) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = kok && (qb * 32 + i * 16 + g * 4 + r < NQ);
-            const float p = ok ? exp2f(sv[r] * c2 - l2[i][r]) : 0.f;
-            pp[i][r] = p;
-            ds[i][r] = p * (dp[r] - dl[i][r]) * a.scale;
+            for (int r = 0; r < 4; ++r) {
+              const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -l2[r]));
+              pp[i][r] = p;
+              ds[i][r] = p * fmaf(dp[r], gs, -dl[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = kok && (qb * 32 + i * 16 + g * 4 + r < NQ);
+              const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -l2[r])) : 0.f;
+              pp[i][r] = p;
+              ds[i][r] = p * fmaf(dp[r], gs, -dl[r]);
+            }
           }
           // dS^T[key][q = 16 i + 4 g + r], 4 consecutive queries = one 8-byte store
           const bf16x4 dsb = {f2bf(ds[i][0]), f2bf(ds[i][1]), f2bf(ds[i][2]), f2bf(ds[i][3])};
-          *(bf16x4*)(dst + (kt * 16 + lc) * (DST_STRIDE * 2) + (i * 16 + g * 4) * 2) = dsb;
+          *(bf16x4*)(dst + (kt * 16 + lc) * (DST4_STRIDE * 2) + (i * 16 + g * 4) * 2) = dsb;
         }
         const bf16x8 pf = {f2bf(pp[0][0]), f2bf(pp[0][1]), f2bf(pp[0][2]), f2bf(pp[0][3]),
                            f2bf(pp[1][0]), f2bf(pp[1][1]), f2bf(pp[1][2]), f2bf(pp[1][3])};
         const bf16x8 dsf = {f2bf(ds[0][0]), f2bf(ds[0][1]), f2bf(ds[0][2]), f2bf(ds[0][3]),
                             f2bf(ds[1][0]), f2bf(ds[1][1]), f2bf(ds[1][2]), f2bf(ds[1][3])};
+        // A operands dO^T, Q^T: k-slot (g, j) = query 16 (j>>2) + 4g + (j&3), transposed reads of the block images
+        const int r0 = g * 4 + tq, r1 = r0 + 16;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dv[t][dt] = mfma16(dot[dt], pf, dv[t][dt]);    // dV^T[d][key] += dO^T[d][q] P[q][key]
-          dk[t][dt] = mfma16(qtt[dt], dsf, dk[t][dt]);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+          const int ch = dt * 2 + (tp >> 1), sub = (tp & 1) * 8;
+          const bf16x8 dot = cat8(lds_tr_read(do_blk + img_off(r0, ch) + sub), lds_tr_read(do_blk + img_off(r1, ch) + sub));
+          const bf16x8 qtt = cat8(lds_tr_read(q_blk + img_off(r0, ch) + sub), lds_tr_read(q_blk + img_off(r1, ch) + sub));
+          dv[t][dt] = mfma16(dot, pf, dv[t][dt]);      // dV^T[d][key] += dO^T[d][q] P[q][key]
+          dk[t][dt] = mfma16(qtt, dsf, dk[t][dt]);     // dK^T[d][key] += Q^T[d][q] dS[q][key]
         }
       }
     }
-    __syncthreads();   // dS^T of this block complete (the other buffer is free again two blocks later)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // Y1: dS^T of this block complete
+    // This wave's share of block qb + 1 must have landed before Y2.  vmcnt retires in order; newer than those two DMA
+    // instructions are at most: DMA(qb + 2) x 2, the two dq stores of block qb - 1, DMA(qb + 3) x 2 -- all six exist for
+    // every block that has a successor (a block with a successor is full: both of its dq stores are issued by every wave),
+    // and without them the wait is only stricter.
+    if (qb + 1 < nblk) {
+      if (qb + QD_NST - 1 < nblk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     {
-      // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: wave -> query tile i = wave >> 2, d tile wave & 3
-      const int i = wave >> 2, dt0 = wave & 3;
-      f32x4 dq[1] = {{0.f, 0.f, 0.f, 0.f}};
+      // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: wave -> d tile, both query tiles of the block
+      f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int ks = 0; ks < 7; ++ks) {
         const int kr = ks * 32 + g * 8 + tq;
-        // B[k = key][col = q]: transposed read of the dS^T image, columns q = 16 i + 4 tp ..
-        const char* pb = dst + kr * (DST_STRIDE * 2) + (i * 16 + tp * 4) * 2;
-        const bf16x8 bfr = cat8(lds_tr_read(pb), lds_tr_read(pb + 4 * DST_STRIDE * 2));
+        const bf16x8 kfr = img_tr_frag(k_img, ks * 32, wave * 16, lane);
 #pragma unroll
-        for (int u = 0; u < 1; ++u) dq[u] = mfma16(img_tr_frag(k_img, ks * 32, (dt0 + u) * 16, lane), bfr, dq[u]);
+        for (int i = 0; i < 2; ++i) {
+          const char* pb = dst + kr * (DST4_STRIDE * 2) + (i * 16 + tp * 4) * 2;
+          const bf16x8 bfr = cat8(lds_tr_read(pb), lds_tr_read(pb + 4 * DST4_STRIDE * 2));
+          dq[i] = mfma16(kfr, bfr, dq[i]);
+        }
       }
-      const int q = qb * 32 + i * 16 + lc;
-      if (q < NQ) {
 #pragma unroll
-        for (int u = 0; u < 1; ++u) {
-          const size_t o = ((size_t)b * NQ + q) * a.dq_rs + h * HD + (dt0 + u) * 16 + g * 4;
-          store_grad4(a.dq + o, a.dq_add ? a.dq_add + o : nullptr, dq[u]);
+      for (int i = 0; i < 2; ++i) {
+        const int q = qb * 32 + i * 16 + lc;
+        if (q < NQ) {
+          const size_t o = ((size_t)b * NQ + q) * a.dq_rs + h * HD + wave * 16 + g * 4;
+          store_grad4(a.dq + o, a.dq_add ? a.dq_add + o : nullptr, dq[i]);
         }
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // Y2: dS^T free again; every wave's share of block qb + 1 is in LDS
   }
-  // ---- dK, dV of this wave's key tiles.  The accumulators hold 4 consecutive d per register quad for key = lane & 15:
-  // stored directly that is 8 bytes per lane in 32-byte row segments.  The images are dead now, so each wave turns its
-  // tiles around through a private LDS slab ([16 keys][64 d] fp32, padded rows) and writes -- and reads the
-  // optional extra gradient -- in whole 128-byte rows, 16 bytes per lane.
-  __syncthreads();                                   // every wave has finished reading the images
+  ATTN_STAMP(3);
+  // ---- dK, dV of this wave's key tiles through a private fp32 LDS slab: whole 128-byte rows, 16 bytes per lane
+  __syncthreads();                                   // every wave has finished reading the images / dS^T
   {
-    constexpr int SROW = 272;                        // bytes per staged key row: 64 fp32 + 16 B pad (conflict-free writes)
-    char* slab = smem + wave * (2 * 16 * SROW);      // [dk | dv] x 16 rows, fp32: rounded to bf16 once, after the add
+    constexpr int SROW = 272;
+    char* slab = smem + wave * (2 * 16 * SROW);
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      const int kt = wave + t * BWD_WAVES;
+    for (int t = 0; t < B4_KT; ++t) {
+      const int kt = wave + t * B4_WAVES;
       if (kt >= ntile) break;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         *(f32x4*)(slab + lc * SROW + (dt * 16 + g * 4) * 4) = dk[t][dt];
-        *(f32x4*)(slab + 16 * SROW + lc * SROW + (dt * 16 + g * 4) * 4) = dv[t][dt];
+        *(f32x4*)(slab + 16 * SROW + lc * SROW + (dt * 16 + g * 4) * 4) = dv[t][dt] * gate;
       }
-      // (same wave writes and reads: the LDS queue is in order and hipcc waits lgkmcnt before the reads' use)
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int row = half * 8 + (lane >> 3), c8 = lane & 7, key = kt * 16 + row;
@@ -458,10 +533,13 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void attn_bwd_kernel(const AttnBwdA
       }
     }
   }
+#ifdef DEVIT_ATTN_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) { stamps[4] = __builtin_amdgcn_s_memtime(); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 constexpr int FWD_LDS = 2 * IMG_BYTES;                                             // 57344: 2 workgroups per CU
-constexpr int BWD_LDS = 4 * IMG_BYTES + 2 * DST_BYTES + 2 * KROWS * 4;             // 152320
 
 }  // namespace
 
@@ -487,11 +565,11 @@ int launch_attn_fwd(const AttnFwdArgs& a, int dtype16, void* stream) {
 int launch_attn_bwd(const AttnBwdArgs& a, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD4_LDS);
     DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "devit_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(BWD_WAVES * 64), BWD_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_bwd4_kernel, dim3(a.B * a.H), dim3(B4_WAVES * 64), BWD4_LDS, (hipStream_t)stream, a);
   DEVIT_LAUNCH_CHECK();
   return DEVIT_OK;
 }
