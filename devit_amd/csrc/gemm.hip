@@ -990,7 +990,9 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   int cfg = 1;
   // N = 256 k + 128 (student qkv: 1152) runs the 256-wide tile with a half-empty last n-tile: its B rows past N are
   // filled from row N-1 and the waves that own them skip the epilogue (variant 0, bf16 / f32 store only)
-  const bool ragged_ok = variant == 0 && light_epi && N % 256 == 128 && N >= 1024;
+  // (also the GELU / dGELU epilogues: hidden 1152 = the compacted student's MLP width at shrink_ratio 0.3)
+  const bool ragged_ok = ((variant == 0 && (light_epi || ep->kind == DEVIT_EPI_GELU_BF16)) ||
+                          (variant == 1 && ep->kind == DEVIT_EPI_DGELU_BF16)) && N % 256 == 128 && N >= 1024;
   if (M % 256 == 0 && (N % 256 == 0 || ragged_ok) && (K >= 1536 || (K >= DEVIT_RAGGED_MIN_K && light_epi) || gelu_epi) && variant != 3) cfg = 3;
   // too few 256x256 tiles to give every CU one (the token-row GEMMs of the lean last block, M = 512): 128x128 tiles
   // quarter the time of the longest workgroup; same accumulation order per output element either way

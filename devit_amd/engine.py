@@ -87,7 +87,6 @@ _side_stream = {}
 _rel_w = {}
 
 
-
 def _relation_weights(gama, layers, device):
     """[gama_q, gama_k, gama_v] / layers as a cached device tensor."""
     key = (float(gama[0]), float(gama[1]), float(gama[2]), int(layers), str(device))

@@ -91,6 +91,30 @@ def test_gemm_persistent_schedule(dev, M, N, K, kind, mv):
     assert bool((out[lim:].float() == 3.0).all())
 
 
+def test_gemm_ragged_gelu_dgelu(dev):
+    """N = 1152 (4.5 x 256: the compacted student's hidden width at shrink_ratio 0.3) through the 256x256 tile with a half-empty
+    last n-tile, GELU (+ pre-activation, + gate) and dGELU epilogues."""
+    from devit_amd import ops, _lib as L
+    M, D, Hd = 5120, 384, 1152
+    x, w1, b1 = rnd((M, D), dev, dtype=BF16), rnd((Hd, D), dev, 0.08, 1, BF16), rnd((Hd,), dev, 0.1, 2)
+    gate = (rnd((Hd,), dev, seed=4) > -0.5).float()
+    pre_ref = x.float() @ w1.float().t() + b1
+    h = torch.full((M, Hd), 3.0, dtype=BF16, device=dev)
+    pre = torch.full((M, Hd), 3.0, dtype=BF16, device=dev)
+    ops.gemm(x, D, 0, w1, D, 0, M, Hd, D, kind=L.EPI_GELU_BF16, out=h, ldc=Hd, bias=b1, colscale=gate, aux=pre, m_valid=5000)
+    bf16_ulp_ok(pre[:5000], pre_ref[:5000])
+    bf16_ulp_ok(h[:5000], (torch.nn.functional.gelu(pre_ref) * gate)[:5000], extra=1e-4)
+    assert bool((h[5000:].float() == 3.0).all()) and bool((pre[5000:].float() == 3.0).all())
+    w2 = rnd((D, Hd), dev, 0.05, 6, BF16)
+    dyv = rnd((M, D), dev, seed=9, dtype=BF16)
+    dh = torch.full((M, Hd), 3.0, dtype=BF16, device=dev)
+    ops.gemm(dyv, D, 0, w2, Hd, 1, M, Hd, D, kind=L.EPI_DGELU_BF16, out=dh, ldc=Hd, colscale=gate, aux_in=pre, m_valid=5000)
+    p32 = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(p32).sum().backward()
+    bf16_ulp_ok(dh[:5000], ((dyv.float() @ w2.float()) * gate * p32.grad)[:5000], extra=1e-4)
+    assert bool((dh[5000:].float() == 3.0).all())
+
+
 def test_gemm_wgrad_persistent(dev):
     """Split-K atomic epilogue with more (tile, slice) work items than persistent workgroups: the ring restarts on every
     tile (the epilogue stages through its LDS)."""
