@@ -26,6 +26,8 @@ def _hand_over(out, main):
         if qkv is None:
             continue
         packed = getattr(qkv[0], "_devit_packed", (qkv[0],))[0]
+        if getattr(packed, "_devit_arena", False):
+            continue                      # tagged by the composite path: lives in the main stream's pool already
         if packed.untyped_storage().nbytes() <= packed.numel() * packed.element_size():    # its own allocation
             packed.record_stream(main)
 

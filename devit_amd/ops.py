@@ -591,6 +591,7 @@ def _encoder_forward_composite(x, cfg, need_grad, nb):
         qkv_rows = mp + (128 if flags & L.BLK_QKV_PAD else 0)
         v = dict(qkv=view(L.ACT_QKV, qkv_rows, 3 * Da, BF16), x2=view(L.ACT_X2, M, D, F32).view(B, N, D),
                  att=view(L.ACT_ATT, M, D, BF16) if cfg.want_att else None)
+        v["qkv"]._devit_arena = True          # a view of an arena from ARENA_ALLOC_STREAM's pool (engine._hand_over)
         views.append(v)
         if bp.module is not None:  # shrink contract (core/imp_rank.py:31,108): post-mask values
             bp.module.mlp.neuron_output = view(L.ACT_H, mp, Hd, BF16)[:M].view(B, N, Hd)

@@ -105,8 +105,15 @@ class Mixup:
     kernels: devit_mix_im2row_bf16 turns the fp32 batch straight into the MIXED batch's bf16 patch rows (the mixed fp32
     images never exist; student and teacher both read those rows) and devit_mix_targets builds the soft targets."""
 
-    def __init__(self, mixup_alpha, cutmix_alpha, prob, switch_prob, label_smoothing, num_classes):
+    def __init__(self, mixup_alpha, cutmix_alpha, prob, switch_prob, label_smoothing, num_classes, precisions=("bf16",)):
         self.ma, self.ca, self.prob, self.sw, self.eps, self.C = mixup_alpha, cutmix_alpha, prob, switch_prob, label_smoothing, num_classes
+        self.set_precisions(*precisions)
+
+    def set_precisions(self, *precisions):
+        """The `precision` of every model that will read the mixed batch (student, teacher): which 16-bit patch rows the
+        fused kernel emits ("bf16" / "f16"); with an "f32" model the mixed batch stays an fp32 image tensor."""
+        self.precisions = tuple(p for p in precisions if p is not None) or ("bf16",)
+        self.row_dtypes = tuple(dict.fromkeys(torch.float16 if p == "f16" else torch.bfloat16 for p in self.precisions if p != "f32"))
 
     def draw(self, H=224, W=224):
         """(mode, lam, box): mode 0 none / 1 mixup / 2 cutmix; lam already corrected to the clipped box area for cutmix."""
@@ -125,7 +132,17 @@ class Mixup:
         from devit_amd import ops
         assert x.shape[0] % 2 == 0, 'Batch size should be even when using this'
         mode, lam, box = self.draw(x.shape[-2], x.shape[-1])
-        return ops.mix_patch_rows(x, mode, lam, box), ops.mix_targets(y, self.C, lam, self.eps)
+        if "f32" in self.precisions or tuple(x.shape[-2:]) != (224, 224):
+            # the exact-fp32 parity models read fp32 images (and the patch-row kernel is built for 224 x 224): timm's formulas on
+            # the image tensor itself, mixed in place like timm does
+            flipped = x.flip(0)
+            if mode == 1:
+                x.mul_(lam).add_(flipped, alpha=1.0 - lam)
+            elif mode == 2:
+                y0, y1, x0, x1 = box
+                x[:, :, y0:y1, x0:x1] = flipped[:, :, y0:y1, x0:x1]
+            return x, ops.mix_targets(y, self.C, lam, self.eps)
+        return ops.mix_patch_rows(x, mode, lam, box, dtypes=self.row_dtypes), ops.mix_targets(y, self.C, lam, self.eps)
 
 
 class CosineEpochs:
@@ -240,9 +257,8 @@ def main(args):
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
         teacher.precision = args.teacher_precision
-        if args.teacher_precision == 'f16':         # Mixup's fused im2row then emits the patch rows in both 16-bit types
-            from devit_amd import ops
-            ops.PATCH_ROW_DTYPES = (torch.bfloat16, torch.float16)
+        if mixup_fn is not None:                    # Mixup's fused im2row emits the patch rows in every 16-bit type a model reads
+            mixup_fn.set_precisions(model.precision, teacher.precision)
 
     flat = ddp.FlatParams(model)
     ddp.broadcast_parameters(flat)          # ranks are seeded seed + rank: rank 0's weights first, then the bf16 copies

@@ -59,9 +59,6 @@ def get_models(args, num_subs, sub_classes, num_classes):
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
         teacher.precision = args.teacher_precision
-        if args.teacher_precision == 'f16':
-            from devit_amd import ops
-            ops.PATCH_ROW_DTYPES = (torch.bfloat16, torch.float16)
     model = MultiViT(model=args.model, drop=args.drop, drop_path=args.drop_path, num_div=num_subs, num_classes_list=sub_classes)
     # sub_size from the constructed backbones (the reference reads a wrong 192 from its config table)
     ens_model = EnsMLP(model=args.model, num_class=num_classes, sub_size=model.backbones[0].embed_dim,
@@ -100,6 +97,8 @@ def main(args):
     mixup_fn = ds.Mixup(args.mixup, args.cutmix, args.mixup_prob, args.mixup_switch_prob, args.smoothing, num_classes) \
         if (args.mixup > 0 or args.cutmix > 0.) else None
     teacher, model, ens_model = get_models(args, len(sub_classes), sub_classes, num_classes)
+    if mixup_fn is not None:        # the fused Mixup + im2row emits the patch rows in every 16-bit type a model of the step reads
+        mixup_fn.set_precisions("bf16", getattr(teacher, "precision", None))
     if args.gates:
         from devit_amd import shrink
         shrink.load_gates(model, args.gates)

@@ -274,6 +274,7 @@ def make_misc(ref_losses):
          neuron_mask=torch.stack(nmask), head_mask=torch.stack(hmask), sparsity=np.array([0.3, 0.5]))
 
     # ---- Mixup / CutMix (timm.data.Mixup, mode='batch') ---------------------------
+    # RESTATED, NOT PINNED: timm is not installed here, so these vectors come from the formulas below, not from timm's code.
     Bm, Cm, eps = 4, 10, 0.1
     img = det_array("mix/img", (Bm, 3, 224, 224))
     yy = det_labels("mix/y", Bm, Cm)

@@ -471,7 +471,9 @@ def _unrow(rows, B):
 def test_mixup_cutmix_im2row_and_targets(dev, golden):
     """devit_mix_im2row_bf16 / devit_mix_targets against timm's Mixup(mode='batch') formulas evaluated by
     tests/golden/make_golden.py (mixup.npz; lambda and the box are inputs): the mixed batch, as bf16 patch rows, equals
-    bf16(formula) -- bit for bit, one rounding; CutMix is an exact copy inside the box; mode 0 is plain im2row."""
+    bf16(formula) -- bit for bit, one rounding; CutMix is an exact copy inside the box; mode 0 is plain im2row.
+    RESTATED, NOT PINNED: timm is absent from the image, so mixup.npz holds SURVEY App. B's restatement of timm's arithmetic,
+    not outputs of timm itself (the same holds for the PatchEmbed conv and SoftTargetCrossEntropy stand-ins of make_golden.py)."""
     from oracle.detgen import det_array, det_labels
     from devit_amd import ops
     g = golden("mixup")

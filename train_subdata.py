@@ -70,9 +70,8 @@ def main(args):
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
         teacher.precision = args.teacher_precision
-        if args.teacher_precision == 'f16':
-            from devit_amd import ops
-            ops.PATCH_ROW_DTYPES = (torch.bfloat16, torch.float16)
+        if mixup_fn is not None:
+            mixup_fn.set_precisions(model.precision, teacher.precision)
 
     flat = ddp.FlatParams(model)
     ddp.broadcast_parameters(flat)          # ranks are seeded seed + rank: rank 0's weights first, then the bf16 copies
