@@ -72,11 +72,12 @@ def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3)
     assert tl % sl == 0, 'The number of student layer can not be divisible by the number of teacher layer'
     rel3 = losses.relation_losses_vector(qkvs[sl // 2 - 1], teacher_qkvs[tl // 2 - 1])     # :91-100, as one [q, k, v] tensor
     if rel3 is not None:
-        # :102-106 on the vector: total = cls + sum_j (gama_j / sl) loss_j (one dot + one add; backward one multiply) and the
+        # :102-106 on the vector: total = cls + sum_j (gama_j / sl) loss_j (one multiply-sum + one add; backward one multiply) and the
         # three logged values as views of loss / sl -- the scalar form costs ~25 tiny kernels per step around the same numbers
         scaled = rel3 / sl
         q_loss, k_loss, v_loss = scaled[0], scaled[1], scaled[2]
-        loss = cls_loss + torch.dot(rel3, _relation_weights(gama, sl, rel3.device))
+        # (an elementwise product + sum, not torch.dot: on ROCm torch.dot is a rocBLAS call, and no vendor BLAS runs on this path)
+        loss = cls_loss + (rel3 * _relation_weights(gama, sl, rel3.device)).sum()
     else:
         q_loss, k_loss, v_loss = losses.relation_losses_packed(qkvs[sl // 2 - 1], teacher_qkvs[tl // 2 - 1])
         q_loss, k_loss, v_loss = q_loss / sl, k_loss / sl, v_loss / sl                  # :102-104
