@@ -55,6 +55,11 @@ class BlockBwdIO(C.Structure):
                 ("dqkv_add", C.c_void_p), ("ws", C.c_void_p * 8), ("lnws_bytes", C.c_size_t)]
 
 
+class IndexJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("idx", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
+                ("src_ld", C.c_int), ("dst_ld", C.c_int), ("mode", C.c_int), ("elem", C.c_int)]
+
+
 class DevitError(RuntimeError):
     pass
 
@@ -81,6 +86,7 @@ SIGNATURES = {
     "devit_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "devit_attn_fwd_rows": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "devit_attn_bwd_rows": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "devit_index_copy": (_I, [_P, _I, _I, _P]),
     "devit_im2row_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "devit_mix_im2row_bf16": (_I, [_P, _P, _P, _I, _I, C.c_double, _I, _I, _I, _I, _P]),
     "devit_mix_targets": (_I, [_P, _P, _I, _I, C.c_double, C.c_double, _P]),

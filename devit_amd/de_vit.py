@@ -161,10 +161,6 @@ class Block(nn.Module):
                     a.gate_key(), m_.gate_key(), w16_ptr(a.qkv), w16_ptr(a.proj), w16_ptr(m_.fc1), w16_ptr(m_.fc2),
                     a.qkv.weight._version, a.proj.weight._version, m_.fc1.weight._version, m_.fc2.weight._version,
                     a.qkv.weight.data_ptr(), a.proj.weight.data_ptr(), m_.fc1.weight.data_ptr(), m_.fc2.weight.data_ptr())
-        if c is not None and c.get("trainable") and (self.training or c.get("stale_after_training")):
-            from . import shrink         # the optimizer rewrote the masters (and their bf16 copies) since the last forward
-            shrink.refresh_compact(self)
-            c["stale_after_training"] = self.training     # the first eval forward after training re-gathers once more
         cached = getattr(self, "_bp_cache", None)
         if cached is not None and cached[0] == key():
             return cached[1]
@@ -278,6 +274,9 @@ def run_blocks(blocks, x, training, want_qkv, want_att, want_enc, grad_ready=Non
     if precision == "f16" and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in blocks for p in b.parameters())):
         raise L.DevitError('precision="f16" is the frozen-teacher forward: no backward kernels read f16 activations; run it '
                            'under torch.no_grad() with requires_grad off, or use precision="bf16"')
+    if any(getattr(b, "_compact", None) is not None and b._compact.get("trainable") for b in blocks):
+        from . import shrink             # the optimizer rewrote the masters (and their bf16 copies) since the last forward
+        shrink.refresh_blocks(blocks)
     bps = [b.block_params(x.device, precision == "f16") for b in blocks]
     if dp_scales == "draw":
         dp_scales = draw_dp_scales(bps, B, x.device, training)

@@ -67,6 +67,9 @@ def compact_block_weights(blk, heads=True):
                 kept_heads=keep_h.tolist(), kept_neurons=keep_n)
 
 
+_serial = [0]          # stamps every compaction (cache keys use it, never id())
+
+
 @torch.no_grad()
 def compact(model, trainable=False):
     """Build the compacted weights of every block of `model` (a devit_amd VisionTransformer, MultiViT sub-models
@@ -79,6 +82,7 @@ def compact(model, trainable=False):
     compact shapes and their results are added into the kept rows / columns of the masters' gradients; masked units get
     exact-zero gradients, as in the masked model (their activations are multiplied by a zero gate there)."""
     report = []
+    _serial[0] += 1
     # DEKD reads q/k/v of ALL heads of the middle block (engine.py:91-92; the gate of models/de_vit.py:77-79 acts on the head
     # OUTPUTS, so a masked head's q/k/v still enter -- and get gradients from -- the relation loss): when training, that
     # block keeps every head in its GEMMs and masks at run time
@@ -101,31 +105,90 @@ def compact(model, trainable=False):
                             qkv_w16=ops.cast_bf16(w["qkv_w"], None), proj_w16=ops.cast_bf16(w["proj_w"], None),
                             fc1_w16=ops.cast_bf16(w["fc1_w"], None), fc2_w16=ops.cast_bf16(w["fc2_w"], None),
                             kept_heads=w["kept_heads"], kept_neurons=w["kept_neurons"], trainable=bool(trainable),
+                            serial=_serial[0] * 100 + len(report),
                             heads_compacted=heads,
-                            heads_idx=torch.as_tensor(w["kept_heads"], dtype=torch.long, device=dev),
                             neurons_idx=w["kept_neurons"].to(dev))
         report.append((len(w["kept_heads"]), w["num_heads"], len(w["kept_neurons"]), w["fc1_w"].shape[0]))
     return report
 
 
+class _JobTable:
+    """A device-resident table of devit_index_job entries (include/devit_hip.h) + what keeps its pointers alive."""
+
+    def __init__(self, jobs, keep, device):
+        import ctypes as C
+        from . import _lib as L
+        arr = (L.IndexJob * len(jobs))(*jobs)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = host.to(device)
+        self.n, self.keep = len(jobs), keep
+        self.biggest = max(j.rows * j.cols for j in jobs)
+
+    def run(self):
+        from ._lib import call, ptr, stream_ptr
+        call("devit_index_copy", ptr(self.table), self.n, max(1, min(64, (self.biggest + 4095) // 4096)), stream_ptr())
+
+
+def _job(src, dst, idx, rows, cols, src_ld, dst_ld, mode, elem):
+    from . import _lib as L
+    return L.IndexJob(src.data_ptr(), dst.data_ptr(), idx.data_ptr(), rows, cols, src_ld, dst_ld, mode, elem)
+
+
+def _index_maps(blk, c):
+    """int32 device maps compact unit -> master unit (-1: padding) for the block's four shapes of copy: qkv rows
+    [3 * Hr * 64], proj columns [Hr * 64], fc1 rows / fc2 columns [Nr]."""
+    m = c.get("maps")
+    if m is None:
+        dev = c["qkv_w16"].device
+        H, Hr, hd = blk.attn.num_heads, c["num_heads"], 64
+        heads = list(c["kept_heads"])
+        hmap = torch.full((Hr,), -1, dtype=torch.int64)
+        hmap[: len(heads)] = torch.as_tensor(heads, dtype=torch.int64)
+        e = torch.arange(hd)
+        cols = torch.where(hmap[:, None] >= 0, hmap[:, None] * hd + e[None, :], torch.full((Hr, hd), -1)).reshape(-1)
+        rows = torch.cat([torch.where(cols >= 0, cols + j * H * hd, cols) for j in range(3)])
+        Nr = c["fc1_w16"].shape[0]
+        nmap = torch.full((Nr,), -1, dtype=torch.int64)
+        nmap[: c["neurons_idx"].numel()] = c["neurons_idx"].cpu()
+        m = c["maps"] = dict(qkv_rows=rows.to(torch.int32).to(dev), head_cols=cols.to(torch.int32).to(dev),
+                             neurons=nmap.to(torch.int32).to(dev))
+    return m
+
+
 @torch.no_grad()
-def refresh_compact(blk):
-    """Re-gather a trainable compacted block's 16-bit weights and fp32 biases from the masters' current values (the fused
-    optimizer rewrites the masters and their bf16 copies in place every step).  Gates are 0/1: nothing to fold."""
+def refresh_blocks(blocks):
+    """Re-gather the 16-bit weights and fp32 biases of every trainable compacted block in `blocks` from the masters' current
+    values (the fused optimizer rewrites the masters and their bf16 copies in place every step): ONE launch over a job
+    table (devit_index_copy); the table is rebuilt when a source or destination moved.  Gates are 0/1: nothing to fold.
+    Blocks in eval mode are refreshed once after training, then left alone."""
     from .de_vit import _w16
-    c = blk._compact
-    hi, ni = c["heads_idx"], c["neurons_idx"]
-    nh, nn_ = hi.numel(), ni.numel()
-    attn, mlp = blk.attn, blk.mlp
-    D, H = attn.qkv.weight.shape[1], attn.num_heads
-    Hr, hd = c["num_heads"], 64
-    q16, p16, f1, f2 = _w16(attn.qkv), _w16(attn.proj), _w16(mlp.fc1), _w16(mlp.fc2)
-    c["qkv_w16"].view(3, Hr, hd, D)[:, :nh].copy_(q16.view(3, H, hd, D).index_select(1, hi))
-    c["proj_w16"].view(D, Hr, hd)[:, :nh].copy_(p16.view(D, H, hd).index_select(1, hi))
-    c["fc1_w16"][:nn_].copy_(f1.index_select(0, ni))
-    c["fc2_w16"][:, :nn_].copy_(f2.index_select(1, ni))
-    c["qkv_b"].view(3, Hr, hd)[:, :nh].copy_(attn.qkv.bias.detach().view(3, H, hd).index_select(1, hi))
-    c["fc1_b"][:nn_].copy_(mlp.fc1.bias.detach().index_select(0, ni))
+    todo = []
+    for blk in blocks:
+        c = getattr(blk, "_compact", None)
+        if c is not None and c.get("trainable") and (blk.training or c.get("stale_after_training")):
+            c["stale_after_training"] = blk.training       # the first eval forward after training re-gathers once more
+            todo.append((blk, c))
+    if not todo:
+        return
+    srcs = [(_w16(b.attn.qkv), _w16(b.attn.proj), _w16(b.mlp.fc1), _w16(b.mlp.fc2), b.attn.qkv.bias, b.mlp.fc1.bias) for b, _ in todo]
+    key = tuple(t.data_ptr() for ss in srcs for t in ss) + tuple(c["serial"] for _, c in todo)
+    owner = todo[0][1]
+    tab = owner.get("refresh_table")
+    if tab is None or tab[0] != key:
+        jobs, keep = [], []
+        for (blk, c), (q16, p16, f1, f2, qb, f1b) in zip(todo, srcs):
+            m = _index_maps(blk, c)
+            D, Hr = blk.attn.qkv.weight.shape[1], c["num_heads"]
+            Nr, Hid = c["fc1_w16"].shape[0], blk.mlp.fc1.weight.shape[0]
+            jobs += [_job(q16, c["qkv_w16"], m["qkv_rows"], 3 * Hr * 64, D, D, D, 0, 2),
+                     _job(p16, c["proj_w16"], m["head_cols"], D, Hr * 64, p16.shape[1], Hr * 64, 1, 2),
+                     _job(f1, c["fc1_w16"], m["neurons"], Nr, D, D, D, 0, 2),
+                     _job(f2, c["fc2_w16"], m["neurons"], f2.shape[0], Nr, Hid, Nr, 1, 2),
+                     _job(qb, c["qkv_b"], m["qkv_rows"], 3 * Hr * 64, 1, 1, 1, 0, 4),
+                     _job(f1b, c["fc1_b"], m["neurons"], Nr, 1, 1, 1, 0, 4)]
+            keep.append((q16, p16, f1, f2, qb, f1b, m))
+        tab = owner["refresh_table"] = (key, _JobTable(jobs, keep, owner["qkv_w16"].device))
+    tab[1].run()
 
 
 def attach_training(blk, bp, c):
@@ -134,34 +197,38 @@ def attach_training(blk, bp, c):
     attn, mlp = blk.attn, blk.mlp
     dev = c["qkv_w16"].device
     D, H, Hr, hd = attn.qkv.weight.shape[1], attn.num_heads, c["num_heads"], 64
-    Nr = c["fc1_w16"].shape[0]
-    hi, ni = c["heads_idx"], c["neurons_idx"]
-    nh, nn_ = hi.numel(), ni.numel()
+    Nr, Hid = c["fc1_w16"].shape[0], mlp.fc1.weight.shape[0]
     slots = c.get("slots")
     if slots is None:
         slots = c["slots"] = dict(qkv_w=ops.GradSlot((3 * Hr * hd, D), dev), qkv_b=ops.GradSlot((3 * Hr * hd,), dev),
                                   proj_w=ops.GradSlot((D, Hr * hd), dev), fc1_w=ops.GradSlot((Nr, D), dev),
                                   fc1_b=ops.GradSlot((Nr,), dev), fc2_w=ops.GradSlot((D, Nr), dev))
     bp.qkv_w, bp.proj_w, bp.fc1_w, bp.fc2_w = slots["qkv_w"], slots["proj_w"], slots["fc1_w"], slots["fc2_w"]
-    bias_slots = (slots["qkv_b"], slots["fc1_b"])
     # the compact biases are plain fp32 tensors read by the forward; their gradients go to slots
-    qkv_b_val, fc1_b_val = c["qkv_b"], c["fc1_b"]
-    bp.qkv_b, bp.fc1_b = _BiasWithSlot(qkv_b_val, bias_slots[0]), _BiasWithSlot(fc1_b_val, bias_slots[1])
+    bp.qkv_b, bp.fc1_b = _BiasWithSlot(c["qkv_b"], slots["qkv_b"]), _BiasWithSlot(c["fc1_b"], slots["fc1_b"])
     bp.masters = [blk.norm1.weight, blk.norm1.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight, attn.proj.bias,
                   blk.norm2.weight, blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias]
+    m = _index_maps(blk, c)
 
     def finish():
+        """Compact weight gradients -> the kept rows / columns of the masters' gradients (one launch), slots zeroed."""
+        if slots["qkv_w"].grad is None:
+            return
         g = ops.grad_buf
         with torch.no_grad():
-            if slots["qkv_w"].grad is not None:
-                g(attn.qkv.weight).view(3, H, hd, D).index_add_(1, hi, slots["qkv_w"].grad.view(3, Hr, hd, D)[:, :nh])
-                g(attn.qkv.bias).view(3, H, hd).index_add_(1, hi, slots["qkv_b"].grad.view(3, Hr, hd)[:, :nh])
-                g(attn.proj.weight).view(D, H, hd).index_add_(1, hi, slots["proj_w"].grad.view(D, Hr, hd)[:, :nh])
-                g(mlp.fc1.weight).index_add_(0, ni, slots["fc1_w"].grad[:nn_])
-                g(mlp.fc1.bias).index_add_(0, ni, slots["fc1_b"].grad[:nn_])
-                g(mlp.fc2.weight).index_add_(1, ni, slots["fc2_w"].grad[:, :nn_])
-                for s_ in slots.values():
-                    s_.grad.zero_()
+            dsts = [g(attn.qkv.weight), g(attn.proj.weight), g(mlp.fc1.weight), g(mlp.fc2.weight), g(attn.qkv.bias), g(mlp.fc1.bias)]
+            srcs = [g(slots[k]) for k in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "fc1_b")]
+            key = tuple(t.data_ptr() for t in dsts + srcs)
+            tab = c.get("scatter_table")
+            if tab is None or tab[0] != key:
+                jobs = [_job(srcs[0], dsts[0], m["qkv_rows"], 3 * Hr * hd, D, D, D, 2, 4),
+                        _job(srcs[1], dsts[1], m["head_cols"], D, Hr * hd, Hr * hd, H * hd, 3, 4),
+                        _job(srcs[2], dsts[2], m["neurons"], Nr, D, D, D, 2, 4),
+                        _job(srcs[3], dsts[3], m["neurons"], D, Nr, Nr, Hid, 3, 4),
+                        _job(srcs[4], dsts[4], m["qkv_rows"], 3 * Hr * hd, 1, 1, 1, 2, 4),
+                        _job(srcs[5], dsts[5], m["neurons"], Nr, 1, 1, 1, 2, 4)]
+                tab = c["scatter_table"] = (key, _JobTable(jobs, (dsts, srcs, m), dev))
+            tab[1].run()                 # (the add modes zero the slots they consumed)
     bp.finish = finish
 
 

@@ -235,6 +235,27 @@ int devit_block_bwd(const devit_block_weights* w, const devit_block_acts* acts, 
                     const devit_block_bwd_io* io, int B, int N, int D, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Index copies of physically shrunk (compacted) blocks that are being TRAINED (distill_sub.py:384-401 trains the gated
+ * student; core/imp_rank.py:65-71,147-153 only mask).  A table of jobs in device memory, one launch:
+ *   mode 0  gather rows     dst[i][c]      = src[idx[i]][c]        (16-bit or f32 elements)
+ *   mode 1  gather columns  dst[r][j]      = src[r][idx[j]]
+ *   mode 2  add rows        dst[idx[i]][c] += src[i][c]            (f32: compact weight gradients into the masters'; the
+ *   mode 3  add columns     dst[r][idx[j]] += src[r][j]             source is an accumulator and is ZEROED by the call)
+ * rows x cols is the extent of the COMPACT (dense) side; idx entries < 0 mark padding units and are skipped; kept
+ * indices are distinct, so the adds need no atomics.  Jobs of one call must not write the same memory.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* src;
+  void* dst;
+  const int* idx;        /* device, rows entries (modes 0, 2) or cols entries (modes 1, 3) */
+  int rows, cols;
+  int src_ld, dst_ld;    /* elements */
+  int mode;
+  int elem;              /* bytes per element: 2 or 4 (modes 2, 3: 4) */
+} devit_index_job;
+int devit_index_copy(const devit_index_job* jobs_device, int njobs, int blocks_per_job, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Patch embedding helpers (timm PatchEmbed used at models/de_vit.py:166-168,258 and token assembly
  * :259-264).  im2row: f32 [B,3,224,224] -> bf16 [B*196][768] with k = c*256 + kh*16 + kw; the
  * projection itself is devit_gemm_bf16 with DEVIT_EPI_PATCH_F32.  embed_tokens writes

@@ -4,7 +4,7 @@ set -e
 NAME=$1; EXTRA=$2
 cd "$(dirname "$0")/../devit_amd/csrc"
 mkdir -p build_$NAME ../../tools/_diag
-for f in api gemm layernorm attention elementwise losses sgemm comm encoder; do
+for f in api gemm layernorm attention elementwise losses sgemm comm encoder shrink; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $EXTRA -c $f.hip -o build_$NAME/$f.o &
 done
 wait
