@@ -31,7 +31,10 @@ class MultiViT(nn.Module):
         from . import ops
         if x.is_cuda and all(getattr(m, "precision", "bf16") == "bf16" for m in self.backbones):
             x = ops.patch_rows(x)
-        feats = [m.forward_features(x) for m in self.backbones]
+        # only the class / distillation tokens of every backbone are read (:36-39): their last blocks run on the token rows
+        from .de_vit import lean_tail
+        with lean_tail(*self.backbones):
+            feats = [m.forward_features(x) for m in self.backbones]
         if 'vit' in self.model:
             return [f['output'] for f in feats]
         return [f['output'][0] for f in feats], [f['output'][1] for f in feats]
