@@ -272,7 +272,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
     header = 'Epoch: [{}]'.format(epoch)
     step = 0
     for samples, targets, _ in metric_logger.log_every(_PreparedBatches(data_loader, device, mixup_fn, None), print_freq, header):
-        outputs = model(samples)                                                     # :258
+        with de_vit.lean_tail(model):                                                # only the logits are read below
+            outputs = model(samples)                                                 # :258
         loss = criterion(inputs=samples, outputs=outputs, labels=targets)            # :259
         if step % print_freq == 0:
             loss_value = loss.item()

@@ -167,7 +167,8 @@ class DistillationLoss(nn.Module):
             return self._loss((logits, logits), None, labels)
         if isinstance(outputs, torch.Tensor):
             raise ValueError("DistillationLoss: the model must return (outputs, outputs_kd) when distilling")
-        with torch.no_grad():
+        from .de_vit import lean_tail
+        with torch.no_grad(), lean_tail(self.teacher_model):       # only the teacher's logits are read
             teacher_outputs = self.teacher_model(inputs)
         return self._loss(outputs, teacher_outputs, labels)
 
@@ -219,7 +220,8 @@ class EnsLoss(nn.Module):
     def forward(self, inputs, stu_outputs, labels):
         if self.distillation_type == 'none':
             return self._cls(stu_outputs, None, labels)
-        with torch.no_grad():
+        from .de_vit import lean_tail
+        with torch.no_grad(), lean_tail(self.teacher_model):       # logits and the last class / distillation tokens are read
             tea = self.teacher_model(inputs, distill_token=True)
         tokens, stu_logits = stu_outputs
         cls_loss = self._cls(stu_logits, tea['output'], labels)          # (1-a) base + a distill, :236-237
