@@ -82,12 +82,12 @@ __device__ __forceinline__ void put_image(char* img, const RowRegs<NT>& r, float
 // (1 KiB) into consecutive LDS bytes, so the image's chunk swizzle goes on the per-lane SOURCE address (lane l of slab s
 // writes row 8 s + l / 8, physical chunk l % 8, which must hold logical chunk (l % 8) ^ swizzle(row)).  Rows >= N cannot
 // be zero-filled by a DMA: they repeat row N - 1 (finite values; every use of a padded key or query is masked to P = 0).
-template <int NWAVES>
+template <int NWAVES, int ROWS = KROWS>
 __device__ __forceinline__ void dma_image(char* img, const __bf16* src, size_t row_stride, int N, int wave, int lane) {
 #pragma unroll
-  for (int it = 0; it < (KROWS / 8 + NWAVES - 1) / NWAVES; ++it) {
+  for (int it = 0; it < (ROWS / 8 + NWAVES - 1) / NWAVES; ++it) {
     const int slab = wave + it * NWAVES;
-    if (slab < KROWS / 8) {
+    if (slab < ROWS / 8) {
       const int row = slab * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
       const __bf16* g = src + (size_t)min(row, N - 1) * row_stride + c * 8;
       __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(img + slab * 1024), 16, 0, 0);
@@ -114,13 +114,23 @@ struct AttnFwdArgs {
 // registers, so the row softmax is in-lane + two shuffles, and the bf16 P values of two key tiles are already
 // the B operand of O^T = V^T P (k-slot (g, j) = key 16*t(j>>2) + 4g + (j&3); V is read transposed with the
 // same key order).  P never touches LDS; each lane ends up with 4 consecutive d of its own query row.
-constexpr int FWD_WAVES = 8;
+// -DDEVIT_ATTN_FWD_WAVES=4 (round-3 experiment, measured null): 4 waves, images of 208 rows (13 key tiles), 53 KB per
+// workgroup -> THREE workgroups per CU instead of two.  Half of a workgroup's life is its prologue (in-kernel stamps,
+// tools/attn_fwd_stamps.py), but a third resident workgroup only makes every prologue longer: 62.6 / 110 us against
+// 62.0 / 111 us per student / teacher launch (profiles/r03_s_attention_fwd_occupancy_null.txt).  The launch runs at the rate
+// the memory system delivers first-touch 128-byte row pieces (2.5-2.8 TB/s), whatever the occupancy.
+#ifndef DEVIT_ATTN_FWD_WAVES
+#define DEVIT_ATTN_FWD_WAVES 8
+#endif
+constexpr int FWD_WAVES = DEVIT_ATTN_FWD_WAVES;
+constexpr int FWD_ROWS = FWD_WAVES == 8 ? KROWS : MAXT * 16;           // rows of the K / V images
+constexpr int FWD_IMG = FWD_ROWS * HD * 2;
 
 template <bool F16>
-__global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnFwdArgs a) {
+__global__ __launch_bounds__(FWD_WAVES * 64, FWD_WAVES == 8 ? 4 : 3) void attn_fwd_kernel(const AttnFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_img = smem;
-  char* v_img = smem + IMG_BYTES;
+  char* v_img = smem + FWD_IMG;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -128,7 +138,13 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
   const size_t rs = (size_t)a.q_rs, krs = (size_t)a.kv_rs;
   const __bf16* qbase = a.q + (size_t)b * NQ * rs + h * HD;
   const float c2 = a.scale * 1.4426950408889634f;  // scores in log2 domain
+#ifdef DEVIT_ATTN_STAMP    // diagnostic build (tools/attn_stamps.py): head_gate carries a u64 stamp buffer, 8 per workgroup
+  unsigned long long* stamps = (unsigned long long*)a.head_gate + (size_t)blockIdx.x * 8;
+  const float gate = 1.0f;
+  if (tid == 0) { stamps[0] = __builtin_amdgcn_s_memrealtime(); stamps[1] = __builtin_amdgcn_s_memtime(); }
+#else
   const float gate = a.head_gate ? a.head_gate[h] : 1.0f;
+#endif
   const int ntile = (NQ + 15) >> 4;                  // query tiles
   const int g = lane >> 4, lc = lane & 15;
   const int tq = (lane >> 2) & 3, tp = lane & 3;     // transposed-read row / column-quad of this lane
@@ -146,10 +162,19 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
   }
   // K and V images by LDS-DMA: no register round trip, no ds_write pass (forward -6 ... -10 % against register staging, same
   // box, profiles/r02_l_attention_dma_prologue.txt); the Q fragments above go straight to registers in MFMA layout
-  dma_image<FWD_WAVES>(k_img, a.k + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
-  dma_image<FWD_WAVES>(v_img, a.v + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
+  dma_image<FWD_WAVES, FWD_ROWS>(k_img, a.k + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
+  dma_image<FWD_WAVES, FWD_ROWS>(v_img, a.v + (size_t)b * N * krs + h * HD, krs, N, wave, lane);
+#ifdef DEVIT_ATTN_STAMP
+  if (tid == 0) stamps[6] = __builtin_amdgcn_s_memtime();      // loads issued
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share has landed; the barrier covers the others'
+#ifdef DEVIT_ATTN_STAMP
+  if (tid == 0) stamps[7] = __builtin_amdgcn_s_memtime();      // ... landed (wave 0)
+#endif
   __syncthreads();
+#ifdef DEVIT_ATTN_STAMP
+  if (tid == 0) stamps[2] = __builtin_amdgcn_s_memtime();      // images complete
+#endif
   const int tmask = N >> 4;                          // first key tile that contains a key >= N
 
 #pragma unroll
@@ -198,7 +223,9 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
     for (int ks = 0; ks < 7; ++ks) {
       const f32x4 p0 = s[2 * ks], p1 = s[2 * ks + 1];
       const bf16x8 pf = cvt8<F16>(p0, p1);
-      const int r0 = ks * 32 + g * 4 + tq, r1 = r0 + 16;   // keys of tile 2ks / 2ks+1 for this lane group
+      // keys of tile 2ks / 2ks+1 for this lane group; tile 13 (keys 208..223) has P = 0 and, in the 208-row image, no rows:
+      // its operand is read from tile 12's rows (any finite values do)
+      const int r0 = ks * 32 + g * 4 + tq, r1 = (FWD_ROWS < KROWS && ks == 6) ? r0 : r0 + 16;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int ch = dt * 2 + (tp >> 1), sub = (tp & 1) * 8;
@@ -215,6 +242,11 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 4) void attn_fwd_kernel(const AttnF
       }
     }
   }
+#ifdef DEVIT_ATTN_STAMP
+  if (tid == 0) stamps[3] = __builtin_amdgcn_s_memtime();      // wave 0's compute + store issue done
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) { stamps[4] = __builtin_amdgcn_s_memtime(); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -539,7 +571,7 @@ __global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnB
 #endif
 }
 
-constexpr int FWD_LDS = 2 * IMG_BYTES;                                             // 57344: 2 workgroups per CU
+constexpr int FWD_LDS = 2 * FWD_IMG;                                               // 57344: two workgroups per CU
 
 }  // namespace
 
