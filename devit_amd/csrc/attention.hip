@@ -90,6 +90,8 @@ __device__ __forceinline__ void dma_image(char* img, const __bf16* src, size_t r
     if (slab < ROWS / 8) {
       const int row = slab * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
       const __bf16* g = src + (size_t)min(row, N - 1) * row_stride + c * 8;
+      // (default cache policy: a non-temporal DMA is 18 % faster from cold HBM -- 51 / 92 against 62 / 113 us forward -- and
+      // no faster in the step, where much of qkv is still in the Infinity Cache: profiles/r03_t_attention_nt_loads.txt)
       __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(img + slab * 1024), 16, 0, 0);
     }
   }
