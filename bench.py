@@ -384,6 +384,7 @@ def main():
     loss_value = float(loss.detach())
     assert loss_value == loss_value, "non-finite loss"
     img_per_s = B * world * args.steps / dt
+    hbm_peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9     # this rank, warm-up + timed steps (torch's allocator: arenas, masters, gradients)
 
     # ---- gradient exchange of one more step: summed bucket all-reduce time and the share of it that ran under backward
     exchange = None
@@ -477,6 +478,7 @@ def main():
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
             "host_ms_per_step_idle_queue": round(host_step_ms, 3),
+            "hbm_peak_allocated_gb": round(hbm_peak_gb, 2),
             "higher_is_better": True, "scaling": "weak",
             "algorithmic_gflop_per_img": GFLOP_PER_IMG_STEP, "executed_gflop_per_img": executed,
             "timing_protocol": f"{args.warmup} untimed steps, then {args.steps} steps wall-clocked between barrier + "
