@@ -9,8 +9,9 @@ Same flags, defaults, output-directory naming, checkpoint files and per-epoch lo
         --teacher-model deit_base_distilled_patch16_224 --teacher-path <dir> --dataset cifar100 --num_division 4 ...
 
 Differences, all host-side: (1) `--synthetic N` trains/evaluates on N on-device random batches per epoch (the image
-has no torchvision / datasets; the JPEG pipeline of data/ is outside the hot path) -- without it a
-dataset provider must be importable as `data.get_dataset.build_division_dataset` (the reference's own module);
+has no torchvision / datasets; the JPEG pipeline of data/ is outside the hot path) -- without it the
+reference's dataset package must be importable as `data.get_dataset` (its `build_division_dataset` / `build_dataset`);
+samplers and loaders are then built as the reference builds them (`build_loaders`);
 (2) bf16 needs no loss scaling: `scaler` in checkpoints is an empty dict; (3) Mixup/CutMix run as device-side
 tensor ops (SURVEY §8f-4 "next").
 """
@@ -97,6 +98,88 @@ class SyntheticLoader:
         # look-ahead teacher forward of step k+1 is still reading its batch while step k runs
         for _ in range(self.steps):
             yield self.img.clone(), self.lab.clone()
+
+
+class RASampler(torch.utils.data.Sampler):
+    """Repeated-augmentation sampler of utils/samplers.py:8-63 (DeiT's): every index `num_repeats` times in a row, the
+    repeats of one sample landing on different ranks (rank r takes positions r, r + world, ...), an epoch truncated to
+    floor(len // 256 * 256 / world) draws per rank; the permutation is seeded with the epoch."""
+
+    def __init__(self, dataset, num_replicas, rank, shuffle=True, num_repeats=3):
+        if num_repeats < 1:
+            raise ValueError("num_repeats should be greater than 0")
+        self.n, self.world, self.rank, self.shuffle, self.repeats, self.epoch = len(dataset), num_replicas, rank, shuffle, num_repeats, 0
+        self.num_samples = int(math.ceil(self.n * num_repeats / num_replicas))
+        self.total_size = self.num_samples * num_replicas
+        self.num_selected_samples = int(math.floor(self.n // 256 * 256 / num_replicas))
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.epoch)
+            idx = torch.randperm(self.n, generator=g)
+        else:
+            idx = torch.arange(self.n)
+        idx = torch.repeat_interleave(idx, repeats=self.repeats, dim=0).tolist()
+        idx += idx[:self.total_size - len(idx)]
+        idx = idx[self.rank:self.total_size:self.world]
+        return iter(idx[:self.num_selected_samples])
+
+    def __len__(self):
+        return self.num_selected_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
+def build_loaders(args, num_classes, device, provider="division", plain_sampler_over="test"):
+    """(train_loader, val_loader, num_classes).  `--synthetic N`: resident random batches.  Otherwise the reference's dataset
+    package must be importable as `data.get_dataset` (its transforms need torchvision + timm, which this image lacks):
+    `build_division_dataset(dataset_path=<data-path>/sub-dataset<k>, args=args)` for distill_sub / train_subdata
+    (distill_sub.py:269-272), `build_dataset(args)` for ensemble (ensemble.py:261); samplers and loaders as
+    distill_sub.py:274-313 builds them -- RASampler by default, the val loader sequential unless --dist-eval, train
+    drop_last.  `plain_sampler_over`: with --no-repeated-aug distill_sub.py:281-283 and train_subdata.py:347-349 build the
+    TRAIN sampler over the TEST set (its length sets the epoch length, and with it the LR schedule); kept, ensemble.py:271-273
+    uses the train set."""
+    if args.synthetic > 0:
+        return (SyntheticLoader(args.synthetic, args.batch_size, num_classes, device, 1234 + utils.get_rank()),
+                SyntheticLoader(max(1, args.synthetic // 8), args.batch_size, num_classes, device, 99), num_classes)
+    try:
+        import importlib
+        gd = importlib.import_module("data.get_dataset")
+    except Exception as e:
+        raise SystemExit("no dataset provider importable (data.get_dataset, the reference's package: needs torchvision + timm); "
+                         "use --synthetic N. " + repr(e))
+    if provider == "division":
+        train_ds, test_ds, num_classes = gd.build_division_dataset(
+            dataset_path=os.path.join(args.data_path, f"sub-dataset{args.start_division}"), args=args)
+    else:
+        train_ds, test_ds, num_classes = gd.build_dataset(args)
+    world, rank = utils.get_world_size(), utils.get_rank()
+    if args.repeated_aug:
+        sampler_train = RASampler(train_ds, num_replicas=world, rank=rank, shuffle=True)
+    else:
+        sampler_train = torch.utils.data.DistributedSampler(test_ds if plain_sampler_over == "test" else train_ds,
+                                                            num_replicas=world, rank=rank, shuffle=True)
+    if args.dist_eval:
+        if len(test_ds) % world != 0:
+            print("Warning: distributed evaluation with an eval set not divisible by the process count: duplicate entries are "
+                  "added to equalise the ranks, which slightly alters the validation results.")
+        sampler_val = torch.utils.data.DistributedSampler(test_ds, num_replicas=world, rank=rank, shuffle=False)
+    else:
+        sampler_val = torch.utils.data.SequentialSampler(test_ds)
+    train_loader = torch.utils.data.DataLoader(train_ds, sampler=sampler_train, batch_size=args.batch_size,
+                                               num_workers=args.num_workers, pin_memory=args.pin_mem, drop_last=True)
+    val_loader = torch.utils.data.DataLoader(test_ds, sampler=sampler_val, batch_size=args.eval_batch_size,
+                                             num_workers=args.num_workers, pin_memory=args.pin_mem, drop_last=False)
+    return train_loader, val_loader, num_classes
+
+
+def set_epoch(loader, epoch):
+    """distill_sub.py:413-414: the distributed samplers reshuffle per epoch."""
+    sampler = getattr(loader, "sampler", None)
+    if hasattr(sampler, "set_epoch"):
+        sampler.set_epoch(epoch)
 
 
 class Mixup:
@@ -222,15 +305,8 @@ def main(args):
     np.random.seed(seed)
     num_classes = NUM_CLASSES[args.dataset] // args.num_division
     args.num_classes = num_classes
-    if args.synthetic > 0:
-        train_loader = SyntheticLoader(args.synthetic, args.batch_size, num_classes, device, 1234 + utils.get_rank())
-        val_loader = SyntheticLoader(max(1, args.synthetic // 8), args.batch_size, num_classes, device, 99)
-    else:
-        try:
-            from data.get_dataset import build_division_dataset      # the reference's dataset package, if on PYTHONPATH
-        except Exception as e:
-            raise SystemExit("no dataset provider importable (data.get_dataset); use --synthetic N. " + str(e))
-        raise SystemExit("real-data loaders are host-side plumbing outside this build; use --synthetic N")
+    train_loader, val_loader, num_classes = build_loaders(args, num_classes, device, provider="division")
+    args.num_classes = num_classes
 
     mixup_fn = None
     if args.mixup > 0 or args.cutmix > 0. or args.cutmix_minmax is not None:
@@ -309,6 +385,8 @@ def main(args):
     output_dir, max_accuracy, start = Path(args.output_dir) / f'sub-dataset{args.start_division}', 0.0, time.time()
     output_dir.mkdir(parents=True, exist_ok=True)
     for epoch in range(args.start_epoch, args.epochs):
+        if args.distributed:
+            set_epoch(train_loader, epoch)
         train_stats = engine.train_1epoch_qkv(model=model, teacher_model=teacher, criterion=criterion, args=args,
                                               data_loader=train_loader, optimizer=optimizer, device=device, epoch=epoch,
                                               loss_scaler=loss_scaler, log=None, max_norm=args.clip_grad, mixup_fn=mixup_fn)

@@ -90,10 +90,7 @@ def main(args):
     sub_classes = [int(c) for c in args.sub_classes]
     num_classes = sum(sub_classes)
     args.num_classes = num_classes
-    if not args.synthetic:
-        raise SystemExit("real-data loaders are host-side plumbing outside this build; use --synthetic N")
-    train_loader = ds.SyntheticLoader(args.synthetic, args.batch_size, num_classes, device, 1234 + utils.get_rank())
-    val_loader = ds.SyntheticLoader(max(1, args.synthetic // 8), args.batch_size, num_classes, device, 99)
+    train_loader, val_loader, _ = ds.build_loaders(args, num_classes, device, provider="whole", plain_sampler_over="train")   # ensemble.py:261-300
     mixup_fn = ds.Mixup(args.mixup, args.cutmix, args.mixup_prob, args.mixup_switch_prob, args.smoothing, num_classes) \
         if (args.mixup > 0 or args.cutmix > 0.) else None
     teacher, model, ens_model = get_models(args, len(sub_classes), sub_classes, num_classes)
@@ -123,6 +120,8 @@ def main(args):
                                args.distillation_tau, args.loss)
     output_dir, max_accuracy, start = Path(args.output_dir), 0.0, time.time()
     for epoch in range(args.start_epoch, args.epochs):
+        if args.distributed:
+            ds.set_epoch(train_loader, epoch)
         train_stats = engine.train_1epoch_ens_disjoint(model, ens_model, criterion, train_loader, optimizer, ens_optimizer,
                                                        device, epoch, None, args, None, mixup_fn=mixup_fn,
                                                        max_norm=args.clip_grad)

@@ -211,6 +211,27 @@ def make_misc(ref_losses):
         json.dump(flops, f, indent=0)
     print("flops.json", flops)
 
+    # ---- repeated-augmentation sampler (utils/samplers.py:8-63): the index stream per (dataset length, world, rank, epoch)
+    spec = importlib.util.spec_from_file_location("_ref_samplers", f"{REF}/utils/samplers.py")
+    sm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sm)
+
+    class _Len:
+        def __init__(self, n): self.n = n
+        def __len__(self): return self.n
+    cases = []
+    for n, world in ((1000, 1), (1000, 4), (2570, 8), (513, 2), (256, 1), (255, 1)):
+        for rank in sorted({0, world - 1}):
+            for epoch in (0, 3):
+                smp = sm.RASampler(_Len(n), num_replicas=world, rank=rank, shuffle=True)
+                smp.set_epoch(epoch)
+                idx = list(smp)
+                cases.append(dict(n=n, world=world, rank=rank, epoch=epoch, length=len(smp), head=idx[:24],
+                                  checksum=int(sum((i + 1) * (v + 1) for i, v in enumerate(idx)) % 1000000007)))
+    with open(os.path.join(HERE, "ra_sampler.json"), "w") as f:
+        json.dump(cases, f)
+    print("ra_sampler.json", len(cases), "cases")
+
     # ---- DistillationLoss (teacher inside the criterion) ------------------------------------------
     B, C = 8, 25
     lo = torch.from_numpy(det_array("dl/lo", (B, C), std=1.5)).requires_grad_(True)

@@ -349,3 +349,62 @@ def test_rank_units_and_masks(tmp_path):
         ho = m.blocks[i].attn.head_output.float().abs().sum((0, 1, 3)).cpu()
         assert bool((no[nm == 0] == 0).all()) and bool((no[nm == 1] > 0).all())
         assert bool((ho[hm == 0] == 0).all()) and bool((ho[hm == 1] > 0).all())
+
+
+@pytest.mark.parametrize("extra,steps", [(["--no-repeated-aug"], 2), ([], 8)])
+def test_distill_sub_on_a_dataset_provider(tmp_path, monkeypatch, extra, steps):
+    """Without --synthetic the CLI takes its datasets from `data.get_dataset.build_division_dataset` (the reference's
+    package; a stand-in with host tensors here), builds the reference's samplers / loaders (distill_sub.py:269-313) and
+    trains and evaluates from pinned host batches: one epoch, the reference's files written, `steps` iterations
+    (--no-repeated-aug: the train sampler runs over the 8-image TEST set as in the reference; default: RASampler, 256 of the
+    3 x 260 repeats at batch 32)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import json
+    import types
+    import distill_sub
+    pkg, mod = types.ModuleType("data"), types.ModuleType("data.get_dataset")
+
+    def tensors(n, seed):
+        g = torch.Generator().manual_seed(seed)
+        return torch.utils.data.TensorDataset(torch.randn((n, 3, 224, 224), generator=g), torch.randint(0, 25, (n,), generator=g))
+    seen = []
+
+    def build_division_dataset(dataset_path, args):
+        seen.append(dataset_path)
+        return tensors(260, 1), tensors(8, 2), 25
+    mod.build_division_dataset = build_division_dataset
+    pkg.get_dataset = mod
+    monkeypatch.setitem(sys.modules, "data", pkg)
+    monkeypatch.setitem(sys.modules, "data.get_dataset", mod)
+    from devit_amd import engine
+    counted = []
+    real = engine.distill_forward
+
+    def counting(*a, **k):
+        counted.append(1)
+        return real(*a, **k)
+    monkeypatch.setattr(engine, "distill_forward", counting)
+    parser = argparse.ArgumentParser(parents=[distill_sub.get_args_parser()])
+    bs = "4" if extra else "32"
+    args = parser.parse_args(["--batch-size", bs, "--eval-batch-size", "8", "--epochs", "1", "--model", "dedeit", "--num_workers", "0",
+                              "--teacher-model", "deit_base_distilled_patch16_224", "--dataset", "cifar100", "--num_division", "4",
+                              "--data-path", str(tmp_path / "data"), "--output_dir", str(tmp_path / "out"), "--warmup-epochs", "0",
+                              "--synthetic", "0", "--teacher-path", ""] + extra)
+    try:
+        distill_sub.main(args)
+    except SystemExit as e:                      # no teacher checkpoint on a real-data run is an error by design
+        assert "teacher checkpoint" in str(e)
+        args.teacher_path = str(tmp_path / "teachers")
+        import devit_amd
+        os.makedirs(os.path.join(args.teacher_path, "sub-dataset0"))
+        torch.save(devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=25).state_dict(),
+                   os.path.join(args.teacher_path, "sub-dataset0", "checkpoint.pth"))
+        counted.clear()
+        distill_sub.main(args)
+    assert seen and seen[-1] == os.path.join(str(tmp_path / "data"), "sub-dataset0")
+    assert len(counted) == steps
+    out = os.path.join(args.output_dir, "sub-dataset0")
+    line = json.loads(open(os.path.join(out, "log.txt")).read().splitlines()[-1])
+    assert line["train_loss"] == line["train_loss"] and 0.0 <= line["test_acc1"] <= 100.0

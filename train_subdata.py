@@ -41,12 +41,10 @@ def main(args):
     np.random.seed(seed)
     num_classes = ds.NUM_CLASSES[args.dataset] // args.num_division
     args.num_classes = num_classes
-    if args.synthetic <= 0:
-        raise SystemExit("real-data loaders are host-side plumbing outside this build; use --synthetic N")
     if args.distillation_token:
         raise SystemExit("--distillation-token (resize_dim models) is outside the DeViT path")
-    train_loader = ds.SyntheticLoader(args.synthetic, args.batch_size, num_classes, device, 1234 + utils.get_rank())
-    val_loader = ds.SyntheticLoader(max(1, args.synthetic // 8), args.batch_size, num_classes, device, 99)
+    train_loader, val_loader, num_classes = ds.build_loaders(args, num_classes, device, provider="division")   # train_subdata.py:335-380
+    args.num_classes = num_classes
     mixup_fn = None
     if args.mixup > 0 or args.cutmix > 0. or args.cutmix_minmax is not None:
         mixup_fn = ds.Mixup(args.mixup, args.cutmix, args.mixup_prob, args.mixup_switch_prob, args.smoothing, num_classes)
@@ -98,6 +96,8 @@ def main(args):
     output_dir.mkdir(parents=True, exist_ok=True)
     max_accuracy, start = 0.0, time.time()
     for epoch in range(args.start_epoch, args.epochs):
+        if args.distributed:
+            ds.set_epoch(train_loader, epoch)
         train_stats = engine.train_one_epoch(model=model, criterion=criterion, data_loader=train_loader, optimizer=optimizer,
                                              device=device, epoch=epoch, loss_scaler=loss_scaler, max_norm=args.clip_grad,
                                              mixup_fn=mixup_fn)
