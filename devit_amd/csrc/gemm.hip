@@ -266,7 +266,9 @@ __device__ __forceinline__ bf16x8 pack8(const float (&x)[8]) {
 // Lanes c and c^8 of each 16-lane row trade one 16-byte chunk so that the two stores of an m-tile each write whole
 // 128-byte rows: on entry lane (g, c) holds row c's bytes [16g, 16g+16) in `a` and [64+16g, 64+16g+16) in `b`; on exit
 // `a` belongs to row (c & 7) and `b` to row 8 + (c & 7), both at byte (c >= 8 ? 64 : 0) + 16g.
-__device__ __forceinline__ void swap_half_rows(bf16x8& a, bf16x8& b, bool hi) {
+template <typename V>   // any 16-byte vector: bf16x8 (64 output columns = one 128-byte row) or f32x4 (two n-tiles = one)
+__device__ __forceinline__ void swap_half_rows(V& a, V& b, bool hi) {
+  static_assert(sizeof(V) == 16, "16-byte chunks");
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
   u32x4 recv;
@@ -281,8 +283,8 @@ __device__ __forceinline__ void swap_half_rows(bf16x8& a, bf16x8& b, bool hi) {
     oa[e] = hi ? recv[e] : ua[e];
     obb[e] = hi ? ub[e] : recv[e];
   }
-  a = __builtin_bit_cast(bf16x8, oa);
-  b = __builtin_bit_cast(bf16x8, obb);
+  a = __builtin_bit_cast(V, oa);
+  b = __builtin_bit_cast(V, obb);
 }
 
 // Per-lane column data of an epilogue: the lane's four column offsets (one per n-tile) and bias / column scale there.
@@ -310,11 +312,98 @@ __device__ __forceinline__ void settle_cols(f32x4 (&bias)[4], f32x4 (&cs)[4]) {
   }
 }
 
+#ifndef DEVIT_F32_FULL_ROWS
+#define DEVIT_F32_FULL_ROWS 1    // fp32 epilogues move whole 128-byte rows per instruction (0: 64-byte halves, the earlier form)
+#endif
+
+// The fp32-output kinds (STORE_F32, PATCH_F32, RESIDUAL_F32) with whole 128-byte rows per memory instruction.  Lane (g, c)
+// holds, per n-tile j, four consecutive floats of row c at column 16 j + 4 g: one instruction per n-tile touches 16 rows x
+// 64 bytes -- half cache lines, twice the transactions of the bytes moved, on an epilogue that runs at the CU's transaction
+// rate.  Here the n-tiles (2 p, 2 p + 1) of a row are one 128-byte line: lanes c and c ^ 8 trade a chunk (swap_half_rows)
+// so that instruction A covers rows 0-7 and instruction B rows 8-15 of the m-tile, every row a whole line; the residual /
+// pos-embed inputs are fetched in that same shape.  Same arithmetic per element as the 64-byte form.
+template <int KIND, int MI, bool FULL, bool F16>
+__device__ __forceinline__ void epilogue_f32_rows(const devit_epilogue& ep, f32x4 (&acc)[MI][4], const int (&noff)[4],
+                                                  const f32x4 (&bias)[4], int lane, int mw, int m_lim, size_t ob) {
+  constexpr int CHI = 2;
+  const int c = lane & 15;
+  const bool hi = c >= 8;
+  const int colx = hi ? 16 : 0;                     // floats: second half of the line
+  auto row_off = [&](int m, int& tok) -> size_t {   // element offset of output row m (PATCH: token remap)
+    if (KIND == DEVIT_EPI_PATCH_F32) {
+      const int b = m / ep.patch_tokens, t = m - b * ep.patch_tokens;
+      tok = ep.extra_tokens + t;
+      return ((size_t)b * (ep.patch_tokens + ep.extra_tokens) + tok) * ep.ldc;
+    }
+    tok = 0;
+    return ob + (size_t)m * ep.ldc;
+  };
+#pragma unroll
+  for (int i0 = 0; i0 < MI; i0 += CHI) {
+    // ---- phase 1: global inputs of the chunk, in the shape they will be stored in
+    f32x4 gin[CHI][2][2];          // [m-tile][line p][rows 0-7 / 8-15]
+    float rsc[CHI][2];
+    size_t rowo[CHI][2];
+    bool okr[CHI][2];
+#pragma unroll
+    for (int u = 0; u < CHI; ++u)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int m = mw + (i0 + u) * 16 + (c & 7) + 8 * r;
+        const bool ok = FULL || m < m_lim;
+        int tok;
+        const size_t o = row_off(m, tok);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int col = noff[2 * p] + colx;
+          if (KIND == DEVIT_EPI_PATCH_F32)
+            gin[u][p][r] = ok ? *(const f32x4*)(ep.pos + (size_t)tok * ep.ldc + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (KIND == DEVIT_EPI_RESIDUAL_F32)
+            gin[u][p][r] = ok ? load_stream((const f32x4*)(ep.res + o + col)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (KIND == DEVIT_EPI_RESIDUAL_F32) rsc[u][r] = (ok && ep.rowscale) ? ep.rowscale[m / ep.rows_per_scale] : 1.0f;
+        rowo[u][r] = o;
+        okr[u][r] = ok;
+      }
+    // ---- phase 2: compute + store
+#pragma unroll
+    for (int u = 0; u < CHI; ++u) {
+      const int i = i0 + u;
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bias[j];
+      if (KIND == DEVIT_EPI_RESIDUAL_F32 && ep.aux) {   // optional bf16 copy of the branch output (output_att): row c, 8 bytes per lane
+        const int m = mw + i * 16 + c;
+        if (FULL || m < m_lim) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) st_out((bf16x4*)((__bf16*)ep.aux + ob + (size_t)m * ep.ldc + noff[j]), cvt4<F16>(v[j]));
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        swap_half_rows(v[2 * p], v[2 * p + 1], hi);
+        const int col = noff[2 * p] + colx;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          f32x4 w = v[2 * p + r];
+          if (KIND == DEVIT_EPI_PATCH_F32) w = w + gin[u][p][r];
+          if (KIND == DEVIT_EPI_RESIDUAL_F32) w = gin[u][p][r] + rsc[u][r] * w;
+          if (okr[u][r]) st_out((f32x4*)((float*)ep.out + rowo[u][r] + col), w);
+        }
+      }
+    }
+  }
+}
+
 template <int KIND, int MI, bool FULL, bool F16 = false>
 __device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 (&acc)[MI][4], const int (&noff)[4],
                                                 const f32x4 (&bias)[4], const f32x4 (&cs)[4], int lane, int mw,
                                                 int m_lim, size_t ob) {
   constexpr bool BF16_OUT = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
+  if constexpr (!BF16_OUT && DEVIT_F32_FULL_ROWS) {
+    epilogue_f32_rows<KIND, MI, FULL, F16>(ep, acc, noff, bias, lane, mw, m_lim, ob);
+    return;
+  }
   constexpr int CHI = 2;
   const int c = lane & 15;
 #pragma unroll
