@@ -125,6 +125,10 @@ struct AttnFwdArgs {
 #define DEVIT_ATTN_FWD_WAVES 8
 #endif
 constexpr int FWD_WAVES = DEVIT_ATTN_FWD_WAVES;
+#ifndef DEVIT_ATTN_OUT_ROWS
+#define DEVIT_ATTN_OUT_ROWS 1        // forward output rows leave as whole 128-byte lines through a per-wave LDS slab (0: 32-byte pieces)
+#endif
+constexpr int OSLAB_ROW = 144;       // bytes per slab row: 128 + 16 (16 rows of one column land on 8 different bank groups)
 constexpr int FWD_ROWS = FWD_WAVES == 8 ? KROWS : MAXT * 16;           // rows of the K / V images
 constexpr int FWD_IMG = FWD_ROWS * HD * 2;
 
@@ -152,15 +156,16 @@ __global__ __launch_bounds__(FWD_WAVES * 64, FWD_WAVES == 8 ? 4 : 3) void attn_f
   const int tq = (lane >> 2) & 3, tp = lane & 3;     // transposed-read row / column-quad of this lane
   constexpr int QT = (MAXT + FWD_WAVES - 1) / FWD_WAVES;   // query tiles per wave
   // Q fragments of ALL this wave's query tiles first, then the K / V images: one exposed HBM latency per workgroup
+  // (fetched in MFMA layout, 16 rows x 64 bytes per instruction; whole 128-byte rows + a lane trade afterwards measured 0.04 ms
+  // per step SLOWER, profiles/r03_B_attention_rows.txt)
   bf16x8 qall[QT][2];
 #pragma unroll
   for (int it = 0; it < QT; ++it) {
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     const int q_ = (wave + it * FWD_WAVES) * 16 + lc;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kk = 0; kk < 2; ++kk)
       qall[it][kk] = (wave + it * FWD_WAVES < ntile && q_ < NQ) ? *(const bf16x8*)(qbase + (size_t)q_ * rs + kk * 32 + g * 8) : z;
-    }
   }
   // K and V images by LDS-DMA: no register round trip, no ds_write pass (forward -6 ... -10 % against register staging, same
   // box, profiles/r02_l_attention_dma_prologue.txt); the Q fragments above go straight to registers in MFMA layout
@@ -235,6 +240,24 @@ __global__ __launch_bounds__(FWD_WAVES * 64, FWD_WAVES == 8 ? 4 : 3) void attn_f
         o[dt] = mfma16t<F16>(vf, pf, o[dt]);         // O^T[d][q] += V^T[d][key] P^T[key][q]
       }
     }
+#if DEVIT_ATTN_OUT_ROWS
+    {
+      // Lane (g, lc) holds O[q = lc][d = 16 dt + 4 g + r]: stored from here, an instruction covers 16 rows x 32 bytes -- quarter
+      // cache lines, four times the transactions of the bytes (ablation: the output stores cost 10 / 25 us of a 62 / 111 us
+      // launch for a quarter of the bytes it reads).  Through this wave's private [16][64] LDS slab instead: two
+      // instructions of eight whole 128-byte rows.
+      const float sc = gate / sum;
+      char* slab = smem + 2 * FWD_IMG + wave * (16 * OSLAB_ROW);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(slab + lc * OSLAB_ROW + (dt * 16 + g * 4) * 2) = cvt4<F16>(o[dt] * sc);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = half * 8 + (lane >> 3), c8 = lane & 7, qr = qt * 16 + row;
+        const bf16x8 v = *(const bf16x8*)(slab + row * OSLAB_ROW + c8 * 16);     // (same wave wrote it: ordered by lgkmcnt)
+        if (qr < NQ) *(bf16x8*)(a.out + ((size_t)b * NQ + qr) * D + h * HD + c8 * 8) = v;
+      }
+    }
+#else
     if (q < NQ) {
       const float sc = gate / sum;
       __bf16* orow = a.out + ((size_t)b * NQ + q) * D + h * HD + g * 4;
@@ -243,6 +266,7 @@ __global__ __launch_bounds__(FWD_WAVES * 64, FWD_WAVES == 8 ? 4 : 3) void attn_f
         *(bf16x4*)(orow + dt * 16) = cvt4<F16>(o[dt] * sc);
       }
     }
+#endif
   }
 #ifdef DEVIT_ATTN_STAMP
   if (tid == 0) stamps[3] = __builtin_amdgcn_s_memtime();      // wave 0's compute + store issue done
@@ -573,7 +597,7 @@ __global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnB
 #endif
 }
 
-constexpr int FWD_LDS = 2 * FWD_IMG;                                               // 57344: two workgroups per CU
+constexpr int FWD_LDS = 2 * FWD_IMG + (DEVIT_ATTN_OUT_ROWS ? FWD_WAVES * 16 * OSLAB_ROW : 0);   // 57344 + 18432: two workgroups per CU
 
 }  // namespace
 

@@ -132,6 +132,31 @@ __device__ __forceinline__ bf16x8 cvt8(f32x4 a, f32x4 b) {
   }
 }
 
+// Lanes c and c^8 of each 16-lane row trade one 16-byte chunk so that the two stores of an m-tile each write whole
+// 128-byte rows: on entry lane (g, c) holds row c's bytes [16g, 16g+16) in `a` and [64+16g, 64+16g+16) in `b`; on exit
+// `a` belongs to row (c & 7) and `b` to row 8 + (c & 7), both at byte (c >= 8 ? 64 : 0) + 16g.  The exchange is its own
+// inverse: applied to chunks LOADED in the second shape it yields the first (attention's Q fragments).
+template <typename V>   // any 16-byte vector: bf16x8 (64 output columns = one 128-byte row) or f32x4 (two n-tiles = one)
+__device__ __forceinline__ void swap_half_rows(V& a, V& b, bool hi) {
+  static_assert(sizeof(V) == 16, "16-byte chunks");
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+  u32x4 recv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned send = hi ? ua[e] : ub[e];
+    recv[e] = __builtin_amdgcn_update_dpp(0u, send, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+  }
+  u32x4 oa, obb;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    oa[e] = hi ? recv[e] : ua[e];
+    obb[e] = hi ? ub[e] : recv[e];
+  }
+  a = __builtin_bit_cast(V, oa);
+  b = __builtin_bit_cast(V, obb);
+}
+
 // Transposed LDS read: within each 16-lane group, lane 4q+p supplies the address of row q,
 // columns 4p..4p+3 of a 4x16 block of 16-bit elements; lane i receives column i (rows 0..3).
 __device__ __forceinline__ bf16x4 lds_tr_read(const void* lds_addr) {

@@ -263,30 +263,6 @@ __device__ __forceinline__ bf16x8 pack8(const float (&x)[8]) {
   return (bf16x8){p[0][0], p[0][1], p[1][0], p[1][1], p[2][0], p[2][1], p[3][0], p[3][1]};
 }
 
-// Lanes c and c^8 of each 16-lane row trade one 16-byte chunk so that the two stores of an m-tile each write whole
-// 128-byte rows: on entry lane (g, c) holds row c's bytes [16g, 16g+16) in `a` and [64+16g, 64+16g+16) in `b`; on exit
-// `a` belongs to row (c & 7) and `b` to row 8 + (c & 7), both at byte (c >= 8 ? 64 : 0) + 16g.
-template <typename V>   // any 16-byte vector: bf16x8 (64 output columns = one 128-byte row) or f32x4 (two n-tiles = one)
-__device__ __forceinline__ void swap_half_rows(V& a, V& b, bool hi) {
-  static_assert(sizeof(V) == 16, "16-byte chunks");
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
-  u32x4 recv;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned send = hi ? ua[e] : ub[e];
-    recv[e] = __builtin_amdgcn_update_dpp(0u, send, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
-  }
-  u32x4 oa, obb;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    oa[e] = hi ? recv[e] : ua[e];
-    obb[e] = hi ? ub[e] : recv[e];
-  }
-  a = __builtin_bit_cast(V, oa);
-  b = __builtin_bit_cast(V, obb);
-}
-
 // Per-lane column data of an epilogue: the lane's four column offsets (one per n-tile) and bias / column scale there.
 template <int KIND>
 __device__ __forceinline__ void load_cols(const devit_epilogue& ep, int lane, int nw, int (&noff)[4], f32x4 (&bias)[4],
