@@ -124,56 +124,80 @@ def cpu_baseline(seconds):
 
 
 def kernel_sources_hash():
-    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, devit_common.h, the C-ABI
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.h, generated *.inc, the C-ABI
     header).  The counter summaries under profiles/ record it (tools/pmc_*.py); a summary taken on other kernels than the
     ones this process runs is reported as stale instead of being passed off as a property of the current tree (there is no
     .git on the GPU box to ask)."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "devit_amd", "csrc", "*.hip"))) + \
-        [os.path.join(ROOT, "devit_amd", "csrc", "devit_common.h"), os.path.join(ROOT, "include", "devit_hip.h")]
+    files = sorted(f for ext in ("*.hip", "*.h", "*.inc") for f in glob.glob(os.path.join(ROOT, "devit_amd", "csrc", ext))) + \
+        [os.path.join(ROOT, "include", "devit_hip.h")]
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
-def committed_counter(pattern, key):
-    """(value, source) of the newest committed rocprofv3 counter summary matching profiles/<pattern> -- the counters cannot be
-    read from inside the process, so they come from separate `--pmc` passes over this same command (tools/gpu_pmc_*.sh).
-    value is None when no summary exists or when it was taken on different kernel sources (source says which)."""
+def pick_profile(pattern, want_hash=None):
+    """The committed summary profiles/<pattern> to cite: the one taken on the kernel sources this process runs
+    (`kernel_sources_hash` inside the file == want_hash; the newest by mtime if several match), else the newest by mtime.
+    Never by file name: 'r03_C_*' sorts before 'r03_w_*' although it is the later set."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    files = glob.glob(os.path.join(ROOT, "profiles", pattern))
     if not files:
         return None, None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    src = {"file": "profiles/" + os.path.basename(files[-1]), "kernel_sources_hash": d.get("kernel_sources_hash"),
-           "current_kernel_sources_hash": kernel_sources_hash()}
+    rows = []
+    for f in files:
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        h = d.get("kernel_sources_hash") if isinstance(d, dict) else None
+        rows.append((want_hash is not None and h == want_hash, os.path.getmtime(f), f, d))
+    if not rows:
+        return None, None
+    rows.sort(key=lambda r: (r[0], r[1], r[2]))
+    return rows[-1][2], rows[-1][3]
+
+
+def committed_counter(pattern, key):
+    """(value, source) of the committed rocprofv3 counter summary matching profiles/<pattern> that was taken on the current
+    kernel sources -- the counters cannot be read from inside the process, so they come from separate `--pmc` passes over
+    this same command (tools/gpu_pmc_*.sh).  value is None when no summary exists or when the only ones there were taken on
+    different kernel sources (source says which)."""
+    cur = kernel_sources_hash()
+    f, d = pick_profile(pattern, cur)
+    if f is None:
+        return None, None
+    src = {"file": "profiles/" + os.path.basename(f), "kernel_sources_hash": d.get("kernel_sources_hash"),
+           "current_kernel_sources_hash": cur}
     src["stale"] = src["kernel_sources_hash"] != src["current_kernel_sources_hash"]
     return (None if src["stale"] else d.get(key)), src
 
 
 def parity_statement():
-    """Which tolerance the benchmarked kernels meet, from the newest committed profiles/*_parity_margins.json (written by the
-    `-m gpu` test session, tests/conftest.py): BASELINE.json asks for logits within 1e-3 rel; the bf16 kernels timed here do
-    not meet that, the exact-fp32 mode (never benchmarked) does."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_parity_margins.json")))
+    """Which tolerance the benchmarked kernels meet, from the committed profiles/*_parity_margins.json (written by the
+    `-m gpu` test session, tests/conftest.py) taken on the current kernel sources (else the newest, marked stale): BASELINE.json
+    asks for logits within 1e-3 rel; the bf16 kernels timed here do not meet that, the exact-fp32 mode (never benchmarked) does."""
     out = {"mode": "bf16", "logits_rel_to_max": None, "top1_exact": True, "bar": 1.5e-2,
            "north_star_1e-3_met_by": 'precision="f32" (2e-6 measured; a few TFLOP/s, not benchmarked)', "source": None}
-    if not files:
+    cur = kernel_sources_hash()
+    f, d = pick_profile("*_parity_margins.json", cur)
+    if f is None:
         return out
-    with open(files[-1]) as f:
-        rows = json.load(f)
+    rows = d["rows"] if isinstance(d, dict) else d        # older files are a bare list of rows (no source hash)
+    file_hash = d.get("kernel_sources_hash") if isinstance(d, dict) else None
     vals = {}
     for which in ("dedeit", "deitb"):
         r = [x for x in rows if f"test_model_forward_vs_golden[{which}]" in x.get("test", "") and abs(x.get("bar", 0) - 1.5e-2) < 1e-9]
         if r:
             vals[which] = round(r[0]["value"], 6)
     out["logits_rel_to_max"] = vals or None
-    out["source"] = "profiles/" + os.path.basename(files[-1]) + " (tests/test_gpu_model.py::test_model_forward_vs_golden, top-1 asserted bit-exact there)"
+    out["source"] = "profiles/" + os.path.basename(f) + " (tests/test_gpu_model.py::test_model_forward_vs_golden, top-1 asserted bit-exact there)"
+    out["kernel_sources_hash"] = file_hash
+    out["stale"] = file_hash != cur
     return out
 
 

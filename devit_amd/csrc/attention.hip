@@ -520,8 +520,11 @@ __global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnB
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // Y1: dS^T of this block complete
-    // This wave's share of block qb + 1 must have landed before Y2.  vmcnt retires in order; newer than those two DMA
-    // instructions are at most: DMA(qb + 2) x 2, the two dq stores of block qb - 1, DMA(qb + 3) x 2 -- all six exist for
+    asm volatile("" ::: "memory");                      // (s_barrier is IntrNoMem: no LDS access may be moved across it)
+    // This wave's share of block qb + 1 must have landed before Y2.  vmcnt retires in order; DMA(qb + 1) was issued at the top of
+    // iteration qb - 2, and newer than its two instructions are EIGHT operations: the two dq stores of block qb - 2, DMA(qb + 2)
+    // x 2, the two dq stores of block qb - 1, DMA(qb + 3) x 2.  vmcnt(6) is therefore stricter than necessary by the two oldest
+    // stores (issued two blocks ago: free); do NOT read the 6 as the exact count and trim the wait by it.  All of these exist for
     // every block that has a successor (a block with a successor is full: both of its dq stores are issued by every wave),
     // and without them the wait is only stricter.
     if (qb + 1 < nblk) {
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnB
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // Y2: dS^T free again; every wave's share of block qb + 1 is in LDS
+    asm volatile("" ::: "memory");
   }
   ATTN_STAMP(3);
   // ---- dK, dV of this wave's key tiles through a private fp32 LDS slab: whole 128-byte rows, 16 bytes per lane

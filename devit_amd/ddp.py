@@ -186,8 +186,9 @@ class BucketedGradReducer:
         # scoped form on (what to try first if the 8-GPU curve shows backward stretching under the all-reduce);
         # DEVIT_RESERVE_CUS=n is the library's permanent form.
         import os
-        self.reserve_cus = int(os.environ.get("DEVIT_RESERVE_CUS_EXCHANGE", "0")) if self.cuda else 0
+        self.reserve_cus = self._parse_reserve(os.environ.get("DEVIT_RESERVE_CUS_EXCHANGE", "0")) if self.cuda else 0
         self._reserved = False
+        self._reserved_before = 0        # what devit_get_reserved_cus() said when the window opened (restored by finish())
         self.timing = False          # bench.py: record events around every bucket (allreduce_ms / overlap_frac)
         self.last_timing = None
         self.reset()
@@ -236,7 +237,8 @@ class BucketedGradReducer:
         view = self.flat.flat_grad[s:e]
         if self.cuda and self.reserve_cus and not self._reserved:
             from . import _lib as L
-            L.call("devit_set_reserved_cus", self.reserve_cus)      # GEMM grids enqueued from here on leave room for the collective
+            self._reserved_before = L.load().devit_get_reserved_cus()   # a permanent DEVIT_RESERVE_CUS survives the window
+            L.call("devit_set_reserved_cus", max(self.reserve_cus, self._reserved_before))      # GEMM grids enqueued from here on leave room for the collective
             self._reserved = True
         if self.cuda:
             ev = torch.cuda.Event()
@@ -261,6 +263,19 @@ class BucketedGradReducer:
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    @staticmethod
+    def _parse_reserve(text):
+        """DEVIT_RESERVE_CUS_EXCHANGE -> a value devit_set_reserved_cus accepts (a multiple of 8 in [0, 128]), checked HERE:
+        a bad value must not surface as an error on the first bucket launch, in the middle of backward, when other ranks may
+        already have collectives enqueued."""
+        try:
+            n = int(text)
+        except (TypeError, ValueError):
+            raise ValueError(f"DEVIT_RESERVE_CUS_EXCHANGE={text!r}: not an integer")
+        if n < 0 or n > 128:
+            raise ValueError(f"DEVIT_RESERVE_CUS_EXCHANGE={n}: must lie in [0, 128]")
+        return n // 8 * 8
+
     def finish(self, average=False):
         """Launch whatever was never reported (unused parameters) and join.  The buffer then holds SUMS over ranks and
         `flat.grad_scale` = 1 / world says so (the optimizer kernel applies it); average=True scales in place instead
@@ -278,7 +293,7 @@ class BucketedGradReducer:
             torch.cuda.current_stream().wait_stream(self.stream)
         if self._reserved:
             from . import _lib as L
-            L.call("devit_set_reserved_cus", 0)
+            L.call("devit_set_reserved_cus", self._reserved_before)
             self._reserved = False
         self.flat.grad_scale = 1.0 / self.world
         if average and self.world > 1:

@@ -511,6 +511,21 @@ model_config = {
 }
 
 
+def check_geometry(name, embed_dim, num_heads, mlp_ratio=4.):
+    """Refuse, at construction and with the reason, a geometry the gfx950 kernels are not built for -- instead of registering a
+    name whose first forward fails deep inside a launch.  The GEMM tiles want every Linear's output width in multiples of 128
+    (csrc/gemm.hip), LayerNorm and the block calls a width in multiples of 128 (csrc/layernorm.hip, encoder.hip), attention
+    64-wide heads (csrc/attention.hip).  Of the names models/deit_vit.py:457-525 registers this excludes the three D = 192 ones
+    (`deit_tiny_patch16_224`, `deit_tiny_distilled_patch16_224`, `vit_tiny_patch16_224`): none of them is on the DeViT path
+    (student `dedeit` is 384 / 6, teachers are DeiT-B 768 / 12 or ViT-L 1024 / 16; README.md:50-68 of the reference)."""
+    hidden = int(embed_dim * mlp_ratio)
+    if embed_dim % 128 or embed_dim != num_heads * 64 or hidden % 128:
+        raise NotImplementedError(
+            f"{name}: embed_dim={embed_dim}, num_heads={num_heads}, hidden={hidden} is not a geometry the MI355X kernels are built "
+            f"for (embed_dim and hidden must be multiples of 128, heads 64 wide); supported registered names: "
+            f"{[n for n, c in model_config.items() if c['embed_dim'] % 128 == 0]}")
+
+
 def _cfg(**kwargs):
     return {'url': '', 'num_classes': 1000, 'input_size': (3, 224, 224), 'pool_size': None, 'crop_pct': .9,
             'interpolation': 'bicubic', 'fixed_input_size': True, 'mean': (0.485, 0.456, 0.406),
@@ -519,7 +534,9 @@ def _cfg(**kwargs):
 
 def _make(name):
     def fn(pretrained=False, pretrained_path=None, **kwargs):
-        model = VisionTransformer(**{**model_config[name], **kwargs})
+        geo = {**model_config[name], **kwargs}
+        check_geometry(name, geo.get('embed_dim', 768), geo.get('num_heads', 12), geo.get('mlp_ratio', 4.))
+        model = VisionTransformer(**geo)
         model.default_cfg = _cfg()
         if pretrained_path is not None and pretrained:
             ckpt = torch.load(pretrained_path, map_location='cpu', weights_only=False)

@@ -419,6 +419,12 @@ def _tail_forward(x, bp, dp, cfg, need_grad, ntok):
     x2o = torch.empty((B, ntok, D), dtype=F32, device=dev)
     linear_fwd(h, bp.fc2_w16, bp.fc2_b, T, out=x2o.view(T, D), kind=L.EPI_RESIDUAL_F32, res=x1.view(T, D), rowscale=dp2,
                rows_per_scale=ntok, dtype16=t16)
+    if getattr(bp, "module", None) is not None:
+        # the shrink contract's debug views (models/de_vit.py:41,77) of THIS block are not produced on the lean path: drop the ones an
+        # earlier full forward left, so a ranking pass run inside lean_tail fails loudly instead of reading stale activations (and the
+        # arena they kept alive is released)
+        bp.module.mlp.neuron_output = None
+        bp.module.attn.head_output = None
     s = None
     if need_grad:
         s = dict(x=x, ln1=ln1, mean1=mean1, rstd1=rstd1, kv=kv, ln1_tok=ln1_tok, q_tok=q_tok, attn_o=attn_o, lse=lse,

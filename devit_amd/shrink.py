@@ -160,13 +160,24 @@ def refresh_blocks(blocks):
     """Re-gather the 16-bit weights and fp32 biases of every trainable compacted block in `blocks` from the masters' current
     values (the fused optimizer rewrites the masters and their bf16 copies in place every step): ONE launch over a job
     table (devit_index_copy); the table is rebuilt when a source or destination moved.  Gates are 0/1: nothing to fold.
-    Blocks in eval mode are refreshed once after training, then left alone."""
+    Blocks in eval mode are refreshed once after training and whenever torch rewrote a master since the last gather (load_state_dict, an EMA
+    swap, broadcast_module: the parameters' version counters), otherwise left alone."""
     from .de_vit import _w16
+
+    def versions(blk):
+        # torch-side rewrites of the masters (load_state_dict / --resume, an EMA swap, ddp.broadcast_module) bump these; the
+        # fused optimizer writes through raw pointers and does not -- that case is `blk.training` below
+        return tuple(p._version for p in (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.mlp.fc1.weight,
+                                          blk.mlp.fc1.bias, blk.mlp.fc2.weight))
     todo = []
     for blk in blocks:
         c = getattr(blk, "_compact", None)
-        if c is not None and c.get("trainable") and (blk.training or c.get("stale_after_training")):
+        if c is None or not c.get("trainable"):
+            continue
+        ver = versions(blk)
+        if blk.training or c.get("stale_after_training") or c.get("master_versions") != ver:
             c["stale_after_training"] = blk.training       # the first eval forward after training re-gathers once more
+            c["master_versions"] = ver
             todo.append((blk, c))
     if not todo:
         return

@@ -115,7 +115,12 @@ def main(args):
     optimizer = torch.optim.AdamW(param_groups(model, args.weight_decay), lr=args.lr, eps=args.opt_eps, betas=betas)
     ens_optimizer = torch.optim.AdamW(param_groups(ens_model, args.weight_decay), lr=args.lr, eps=args.opt_eps, betas=betas)
     lr_scheduler, ens_lr_scheduler = ds.CosineEpochs(optimizer, args), ds.CosineEpochs(ens_optimizer, args)   # :345-346
-    base = losses.SoftTargetCrossEntropy() if mixup_fn is not None else torch.nn.CrossEntropyLoss()
+    if mixup_fn is not None:                 # ensemble.py:350-357: smoothing is handled by the mixup label transform
+        base = losses.SoftTargetCrossEntropy()
+    elif args.smoothing:
+        base = losses.LabelSmoothingCrossEntropy(smoothing=args.smoothing)
+    else:
+        base = torch.nn.CrossEntropyLoss()
     criterion = losses.EnsLoss(base, teacher, args.model, args.distillation_type, args.distillation_alpha,
                                args.distillation_tau, args.loss)
     output_dir, max_accuracy, start = Path(args.output_dir), 0.0, time.time()

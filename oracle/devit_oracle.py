@@ -28,6 +28,10 @@ GEOMETRY = {
     "deit_base_patch16_224": dict(embed_dim=768, depth=12, num_heads=12, distilled=False),
     "deit_tiny_distilled_patch16_224": dict(embed_dim=192, depth=12, num_heads=3, distilled=True),
     "deit_base_distilled_patch16_224": dict(embed_dim=768, depth=12, num_heads=12, distilled=True),
+    # models/deit_vit.py:487-525 (vit_large is distill_sub.py:141's default --teacher-model)
+    "vit_tiny_patch16_224": dict(embed_dim=192, depth=12, num_heads=3, distilled=False),
+    "vit_base_patch16_224": dict(embed_dim=768, depth=12, num_heads=12, distilled=False),
+    "vit_large_patch16_224": dict(embed_dim=1024, depth=24, num_heads=16, distilled=False),
 }
 LN_EPS = 1e-6  # models/de_vit.py:163 partial(nn.LayerNorm, eps=1e-6)
 

@@ -44,7 +44,12 @@ def pytest_sessionfinish(session, exitstatus):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
+        try:
+            import bench
+            h = bench.kernel_sources_hash()      # which kernel sources these margins were measured on (bench.parity_statement)
+        except Exception:
+            h = None
         with open(os.path.join(out, "parity_margins.json"), "w") as f:
-            json.dump(_MARGINS, f, indent=0)
+            json.dump({"kernel_sources_hash": h, "rows": _MARGINS}, f, indent=0)
     except OSError:
         pass

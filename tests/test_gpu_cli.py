@@ -137,6 +137,38 @@ def test_ensemble_cli(tmp_path):
     assert line["train_loss"] == line["train_loss"] and "test_acc1" in line
 
 
+@pytest.mark.parametrize("extra,expect", [([], "SoftTargetCrossEntropy"),
+                                          (["--mixup", "0", "--cutmix", "0"], "LabelSmoothingCrossEntropy"),
+                                          (["--mixup", "0", "--cutmix", "0", "--smoothing", "0"], "CrossEntropyLoss")])
+def test_ensemble_base_criterion_selection(tmp_path, monkeypatch, extra, expect):
+    """ensemble.py:350-357 picks the base criterion the way distill_sub.py:345-352 does: SoftTargetCrossEntropy with mixup,
+    LabelSmoothingCrossEntropy(--smoothing, default 0.1) without it, nn.CrossEntropyLoss with neither."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import argparse
+    import json
+    import ensemble
+    from devit_amd import losses
+    seen = []
+    real = losses.EnsLoss
+
+    class Rec(real):
+        def __init__(self, base, *a, **k):
+            seen.append(base)
+            super().__init__(base, *a, **k)
+    monkeypatch.setattr(losses, "EnsLoss", Rec)
+    parser = argparse.ArgumentParser(parents=[ensemble.get_args_parser()], conflict_handler='resolve')
+    args = parser.parse_args(["--synthetic", "2", "--batch-size", "4", "--epochs", "1", "--model", "dedeit",
+                              "--teacher-model", "deit_base_distilled_patch16_224", "--output_dir", str(tmp_path)] + extra)
+    args.output_dir = str(tmp_path)
+    ensemble.main(args)
+    assert type(seen[0]).__name__ == expect
+    if expect == "LabelSmoothingCrossEntropy":
+        assert seen[0].smoothing == 0.1
+    line = json.loads(open(os.path.join(str(tmp_path), "log.txt")).read().splitlines()[-1])
+    assert line["train_loss"] == line["train_loss"]
+
+
 @pytest.mark.parametrize("extra", [[], ["--distillation-type", "hard"], ["--mixup", "0", "--cutmix", "0", "--distillation-type", "soft"]])
 def test_train_subdata_cli(tmp_path, extra):
     """train_subdata.py (teacher / fine-tuning loop, DistillationLoss with the teacher inside the criterion)."""

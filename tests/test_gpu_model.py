@@ -508,6 +508,31 @@ def test_nondistilled_devit_vs_oracle(dev):
         assert chk(rel(p.grad, g_ref.numpy()), 3e-2), (name, rel(p.grad, g_ref.numpy()))
 
 
+def test_vit_large_teacher_forward_vs_oracle(dev):
+    """`vit_large_patch16_224` -- the DEFAULT --teacher-model of distill_sub.py:141 (models/deit_vit.py:517-525: 1024 wide, 24
+    blocks, 16 heads, one class token) -- through the HIP path at bs 2 against the CPU oracle: eval logits, top-1, and the
+    q / k / v views of the block DEKD would read (teacher_layer_num // 2 - 1 = 11, engine.py:91-92)."""
+    import devit_amd
+    geom = O.GEOMETRY["vit_large_patch16_224"]
+    st = O.make_state(geom, C, "L")
+    m = devit_amd.create_model("vit_large_patch16_224", num_classes=C).to(dev).eval()
+    m.load_state_dict(st)
+    assert len(m.blocks) == 24 and m.embed_dim == 1024 and m.blocks[0].attn.num_heads == 16
+    img = torch.from_numpy(det_array("vit_large", (2, 3, 224, 224), std=0.7))
+    with torch.no_grad():
+        ref = O.forward(st, geom, img, training=False)
+        out = m(img.to(dev), output_qkv=True)
+    assert isinstance(out["output"], torch.Tensor) and out["output"].shape == (2, C)
+    assert chk(rel(out["output"], ref["output"].numpy()), 2e-2)
+    assert torch.equal(out["output"].argmax(1).cpu(), ref["output"].argmax(1))
+    assert len(out["qkv"]) == 24
+    for got, want in zip(out["qkv"][11], ref["qkv"][11]):
+        assert got.shape == (2, 16, 197, 64) and chk(rel(got, want.numpy()), 2e-2)
+    with torch.no_grad():                       # the plain call: tensor, not dict (models/de_vit.py:316-325)
+        plain = m(img.to(dev))
+    assert torch.equal(plain, out["output"])
+
+
 # ------------------------------------------------------------------------------------------ batch-size edges
 def test_batch_invariance_and_ragged_batches(models, dev):
     """Ragged inputs: batch sizes that fill no tile (1, 3, 19 images = 198 / 594 / 3762 token rows), changing from call

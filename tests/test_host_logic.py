@@ -23,6 +23,13 @@ def test_registry_semantics():
     assert m.num_classes == 25 and m.embed_dim == 384 and len(m.blocks) == 12
     assert de_vit.model_config["dedeit"]["embed_dim"] == 384
     assert de_vit.model_config["deit_base_distilled_patch16_224"]["embed_dim"] == 768
+    # every registered name either runs or refuses AT CONSTRUCTION with the reason (the D = 192 names of models/deit_vit.py:457-525
+    # do not fit the kernels' tiles; nothing on the DeViT path uses them)
+    for name in ("deit_tiny_patch16_224", "deit_tiny_distilled_patch16_224", "vit_tiny_patch16_224"):
+        with pytest.raises(NotImplementedError, match="multiples of 128"):
+            registry.create_model(name, num_classes=10)
+    with pytest.raises(NotImplementedError):
+        registry.create_model("dedeit", embed_dim=320, num_heads=5)
 
 
 def test_statedict_abi():
@@ -237,3 +244,37 @@ def test_importance_ranking_matches_reference():
         shrink._blocks = real
     for i, (hm, nm) in enumerate(pol):
         assert np.array_equal(hm.numpy(), g["head_mask"][i]) and np.array_equal(nm.numpy(), g["neuron_mask"][i])
+
+
+def test_bench_cites_the_profile_taken_on_the_current_kernel_sources(tmp_path, monkeypatch):
+    """bench.committed_counter / parity_statement pick the summary whose kernel_sources_hash equals the current one --
+    never the lexicographically last file name ('r99_C_*' sorts before 'r99_w_*': round 3's driver line cited the stale set
+    and reported traffic / mfma_busy as null)."""
+    import json
+    import time
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    cur = bench.kernel_sources_hash()
+    (prof / "r99_C_pmc_traffic.json").write_text(json.dumps({"kernel_sources_hash": cur, "traffic_bytes_per_launch": 111}))
+    (prof / "r99_C_pmc_mfma.json").write_text(json.dumps({"kernel_sources_hash": cur, "mfma_busy": 0.5}))
+    (prof / "r99_C_parity_margins.json").write_text(json.dumps({"kernel_sources_hash": cur, "rows": [
+        {"test": "tests/test_gpu_model.py::test_model_forward_vs_golden[dedeit]", "line": 1, "value": 0.008, "bar": 1.5e-2}]}))
+    time.sleep(0.02)       # the stale set is NEWER by mtime and LATER by name: the hash must still win
+    (prof / "r99_w_pmc_traffic.json").write_text(json.dumps({"kernel_sources_hash": "0" * 16, "traffic_bytes_per_launch": 222}))
+    (prof / "r99_w_pmc_mfma.json").write_text(json.dumps({"kernel_sources_hash": "0" * 16, "mfma_busy": 0.1}))
+    (prof / "r99_w_parity_margins.json").write_text(json.dumps([
+        {"test": "tests/test_gpu_model.py::test_model_forward_vs_golden[dedeit]", "line": 1, "value": 0.001, "bar": 1.5e-2}]))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_sources_hash", lambda: cur)
+    v, src = bench.committed_counter("*_pmc_traffic.json", "traffic_bytes_per_launch")
+    assert v == 111 and src["file"].endswith("r99_C_pmc_traffic.json") and src["stale"] is False
+    v, src = bench.committed_counter("*_pmc_mfma.json", "mfma_busy")
+    assert v == 0.5 and src["stale"] is False
+    ps = bench.parity_statement()
+    assert ps["logits_rel_to_max"] == {"dedeit": 0.008} and "r99_C_" in ps["source"] and ps["stale"] is False
+    # nothing matches the current sources: the newest by mtime is cited and marked stale, its value withheld
+    monkeypatch.setattr(bench, "kernel_sources_hash", lambda: "f" * 16)
+    v, src = bench.committed_counter("*_pmc_traffic.json", "traffic_bytes_per_launch")
+    assert v is None and src["stale"] is True and src["file"].endswith("r99_w_pmc_traffic.json")
+    assert bench.parity_statement()["stale"] is True
