@@ -971,6 +971,169 @@ void gemm_kernel(const GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Four-wave 256x256x64 kernel (round 4): one wave per SIMD, each a 128 x 128 sub-tile with its 256 accumulator registers in
+// a[0:255], the K loop one hand-scheduled inline-asm statement (gemm4_kloop.inc, generated by tools/gen_gemm4.py: register plan,
+// ring protocol and operand list are documented there).  Row-major x row-major operands (the forward Linear layers), every
+// DIRECT epilogue kind; same LDS images, same swizzles, same tile order and the same accumulation order per output element as
+// the eight-wave ping-pong kernel above (bit-identical results).  Why: the eight-wave kernel's epilogue runs two waves per SIMD
+// through one vector-issue port with the MFMA pipe idle (21-36 % of every tile), and its K-step is a serial chain of four barrier
+// intervals; a lone wave with 512 registers keeps both k-halves' fragments in registers, needs one barrier per K-step and a third
+// fewer LDS bytes per flop -- provided the loop is hand-placed (hipcc's schedule of it was issue-bound).
+#include "gemm4_kloop.inc"
+
+template <int KIND, bool F16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gemm4_kernel(const GemmArgs g) {
+  static_assert(KIND != DEVIT_EPI_ATOMIC_F32 && KIND != DEVIT_EPI_DGELU_BF16 && !F16, "forward layouts, DIRECT epilogues, bf16");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 256, NWAVES = 4;
+  constexpr bool PAIRED = KIND == DEVIT_EPI_STORE_BF16 || KIND == DEVIT_EPI_GELU_BF16;
+  constexpr int A_TILE_BYTES = BM * BK * 2, B_TILE_BYTES = BN * BK * 2, B_RING = 3 * A_TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  int first, last;
+  {
+    const int q = g.total_tiles >> 3, r = g.total_tiles & 7;
+    const int start = xcd * q + min(xcd, r);
+    first = start + idx;
+    last = start + q + (xcd < r ? 1 : 0);
+  }
+  if (first >= last) return;
+#ifdef DEVIT_GEMM4_STAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tiles, K loop, epilogue, d0 (entry reads), d1 (phase 1), d2 (middle), d3 (phase 2), first tile's loop
+#endif
+
+  const unsigned lda64 = (unsigned)g.lda * 64u, ldb64 = (unsigned)g.ldb * 64u;
+  const unsigned wave_lds = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)wave * 8192u;
+
+  // prologue: stages 0 and 1 of the first tile, in the order the K loop keeps (A(t), B(t), A(t + 1), B(t + 1))
+  TileRef ct = decode_tile<BM, BN, false, false>(g, first);
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    stage_tile<false, BM, NWAVES>(ct.a, g.lda, (ct.kt0 + st) * BK, 0, 0, smem + st * A_TILE_BYTES, wave, lane);
+    stage_tile<false, BN, NWAVES>(ct.b, g.ldb, (ct.kt0 + st) * BK, 0, 0, smem + B_RING + st * B_TILE_BYTES, wave, lane);
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  unsigned g3 = 0, g2 = B_RING;     // LDS byte offsets of the slots that hold stage 0 of the tile about to start
+  const unsigned wv = (unsigned)wave;
+
+  for (int tile = first; tile < last; tile += stride) {
+    const bool has_next = tile + stride < last;
+    const TileRef nt = has_next ? decode_tile<BM, BN, false, false>(g, tile + stride) : ct;
+    const __bf16* a_ptr = ct.a + (size_t)ct.kt0 * BK;
+    const __bf16* b_ptr = ct.b + (size_t)ct.kt0 * BK;
+    const __bf16* a_next = nt.a + (size_t)nt.kt0 * BK;
+    const __bf16* b_next = nt.b + (size_t)nt.kt0 * BK;
+    const unsigned nk = (unsigned)ct.nk;
+    const devit_epilogue& ep = g.ep;
+    // per-lane constants of the K loop (byte offsets inside an LDS slot / from a tile's operand pointer).  Tile-invariant, but
+    // recomputed per tile from an opaque copy of the lane index (~60 VALU instructions): kept alive across the epilogue they
+    // were the values hipcc chose to spill to scratch, and their reloads are vector-memory operations in front of the loop.
+    //   fragment reads: tile index x (m-tile of A, n-tile of B), k-half kk -> VAR[kk][x & 1] + 4096 (x >> 1), see read_frag()
+    //   LDS-DMA source: slab i of this wave (8 rows of 128 bytes) -> dma[i & 3] (+ 32 rows for i >= 4), see lane_offset()
+    unsigned dsA[4], dsB[4], dmaA[4], dmaB[4];
+    {
+      int lane_k;    // = lane, from nothing (v_mbcnt): even `lane` itself, kept alive across the loop, was spilled
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_k));
+      const int c = lane_k & 15, gq = lane_k >> 4;
+  #pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+  #pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          const int rowA = wm * 128 + 16 * par + c;
+          dsA[kk * 2 + par] = (unsigned)(rowA * 128 + (((kk * 4 + gq) ^ swz_row(rowA)) * 16));
+          const int rowB = wn * 128 + tile_row<PAIRED>(par, c);
+          dsB[kk * 2 + par] = (unsigned)(rowB * 128 + (((kk * 4 + gq) ^ swz_row(rowB)) * 16));
+        }
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dmaA[i] = lane_offset<false, BM, NWAVES>(g.lda, wave, lane_k, i, BM);
+        dmaB[i] = lane_offset<false, BN, NWAVES>(g.ldb, wave, lane_k, i, BN);
+      }
+    }
+    unsigned t0, t1, t2, t3;
+#ifdef DEVIT_GEMM4_STAMP   // diagnostic build (tools/gemm4_stamps.py): cycles per tile in the loop's segments, summed per wave
+    unsigned d0, d1, d2, d3;
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+    asm volatile(DEVIT_GEMM4_KLOOP_STAMPED_ASM
+                 : [g3] "+s"(g3), [g2] "+s"(g2), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+                   [d0] "=&s"(d0), [d1] "=&s"(d1), [d2] "=&s"(d2), [d3] "=&s"(d3)
+                 : [aptr] "s"(a_ptr), [bptr] "s"(b_ptr), [anext] "s"(a_next), [bnext] "s"(b_next), [nk] "s"(nk),
+                   [lda64] "s"(lda64), [ldb64] "s"(ldb64), [wlds] "s"(wave_lds), [wv] "s"(wv),
+                   [dsa0] "v"(dsA[0]), [dsa1] "v"(dsA[1]), [dsa2] "v"(dsA[2]), [dsa3] "v"(dsA[3]),
+                   [dsb0] "v"(dsB[0]), [dsb1] "v"(dsB[1]), [dsb2] "v"(dsB[2]), [dsb3] "v"(dsB[3]),
+                   [dmaa0] "v"(dmaA[0]), [dmaa1] "v"(dmaA[1]), [dmaa2] "v"(dmaA[2]), [dmaa3] "v"(dmaA[3]),
+                   [dmab0] "v"(dmaB[0]), [dmab1] "v"(dmaB[1]), [dmab2] "v"(dmaB[2]), [dmab3] "v"(dmaB[3])
+                 : DEVIT_GEMM4_KLOOP_STAMPED_CLOBBERS);
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+    st_sum[0] += 1; st_sum[1] += ts1 - ts0; st_sum[3] += d0; st_sum[4] += d1; st_sum[5] += d2; st_sum[6] += d3;
+    if (tile == first) st_sum[7] = ts1 - ts0;
+#else
+    asm volatile(DEVIT_GEMM4_KLOOP_ASM
+                 : [g3] "+s"(g3), [g2] "+s"(g2), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [aptr] "s"(a_ptr), [bptr] "s"(b_ptr), [anext] "s"(a_next), [bnext] "s"(b_next), [nk] "s"(nk),
+                   [lda64] "s"(lda64), [ldb64] "s"(ldb64), [wlds] "s"(wave_lds), [wv] "s"(wv),
+                   [dsa0] "v"(dsA[0]), [dsa1] "v"(dsA[1]), [dsa2] "v"(dsA[2]), [dsa3] "v"(dsA[3]),
+                   [dsb0] "v"(dsB[0]), [dsb1] "v"(dsB[1]), [dsb2] "v"(dsB[2]), [dsb3] "v"(dsB[3]),
+                   [dmaa0] "v"(dmaA[0]), [dmaa1] "v"(dmaA[1]), [dmaa2] "v"(dmaA[2]), [dmaa3] "v"(dmaA[3]),
+                   [dmab0] "v"(dmaB[0]), [dmab1] "v"(dmaB[1]), [dmab2] "v"(dmaB[2]), [dmab3] "v"(dmaB[3])
+                 : DEVIT_GEMM4_KLOOP_CLOBBERS);
+#endif
+    // v1: the epilogue's column data (bias, column scale) is fetched after the loop (hipcc waits vmcnt(0) for it: the loop's last
+    // requests drain with it).  Not before the loop: a counted load consumed after the K loop gets the same vmcnt(0) (hipcc does
+    // not see the loop's LDS-DMA), a wait placed in front of the loop would also wait for the previous tile's epilogue stores, and
+    // 64 more registers live across the loop (which owns v128-v255) spilled.
+    // The epilogue's per-lane values are derived from an opaque copy of the lane index made HERE: derived from `lane` itself, hipcc
+    // hoists them out of the tile loop and keeps them alive across the K loop (dozens of registers: scratch spills, whose reloads
+    // are vector-memory operations in front of the loop's counted waits).
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    int noff[2][4];
+    f32x4 bias[2][4], cs[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) load_cols<KIND>(ep, lane_e, ct.n0 + wn * 128 + h * 64, noff[h], bias[h], cs[h]);
+    const size_t ob = (size_t)ct.bz * ep.out_batch_stride;
+    const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
+    const bool full = ct.m0 + BM <= m_lim;
+    auto chunk = [&](auto hc, auto ic) {
+      constexpr int H = decltype(hc)::value, I0 = decltype(ic)::value;
+      f32x4 acc[2][4];
+      gemm4_read_acc<H, I0>(acc);
+      const int mw = ct.m0 + wm * 128 + I0 * 16;
+      if (full) epilogue_direct<KIND, 2, true, F16>(ep, acc, noff[H], bias[H], cs[H], lane_e, mw, m_lim, ob);
+      else epilogue_direct<KIND, 2, false, F16>(ep, acc, noff[H], bias[H], cs[H], lane_e, mw, m_lim, ob);
+    };
+    auto half = [&](auto hc) {
+      chunk(hc, std::integral_constant<int, 0>());
+      chunk(hc, std::integral_constant<int, 2>());
+      chunk(hc, std::integral_constant<int, 4>());
+      chunk(hc, std::integral_constant<int, 6>());
+    };
+    half(std::integral_constant<int, 0>());
+    half(std::integral_constant<int, 1>());
+#ifdef DEVIT_GEMM4_STAMP
+    st_sum[2] += __builtin_amdgcn_s_memtime() - ts1;
+#endif
+    ct = nt;
+  }
+  wait_vmcnt<0>();   // the last tile requested two stages nobody reads: they must have landed before the workgroup's LDS is released
+#ifdef DEVIT_GEMM4_STAMP
+  if (g.ep.pos && KIND != DEVIT_EPI_PATCH_F32 && lane == 0) {
+    unsigned long long* dbg = (unsigned long long*)g.ep.pos + ((size_t)blockIdx.x * NWAVES + wave) * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dbg[q] = st_sum[q];
+    dbg[8] = t_entry; dbg[9] = __builtin_amdgcn_s_memtime(); dbg[10] = rt_entry; dbg[11] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // CUs the persistent grids leave free (devit_set_reserved_cus): -1 = not set yet, take DEVIT_RESERVE_CUS from the environment
@@ -1150,8 +1313,37 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
         DEVIT_CHECK(false, DEVIT_ERR_ARG, "devit_gemm_bf16: layout %d with epilogue %d is not instantiated", variant, ep->kind); \
     }                                                                                                          \
   } while (0)
-  if (cfg == 3) DEVIT_LAUNCH_GEMM(256, 256, 2, 4, 2);
+  // the four-wave kernel takes the 256x256 launches it is built for: row-major x row-major, whole 256-wide n-tiles, bf16
+  // OPT-IN (DEVIT_GEMM4=1, read per call so that a test can switch it): measured at parity with the eight-wave kernel -- both
+  // run their K-step at ~2600-2700 cycles, the rate at which a CU's LDS-DMA requests are served under full-chip load
+  // (profiles/r04_a_gemm_four_wave.txt)
+  const char* gemm4_env = getenv("DEVIT_GEMM4");
+  const bool use4 = gemm4_env && atoi(gemm4_env) != 0 && cfg == 3 && variant == 0 && !f16 && N % 256 == 0 && K / BK >= 3 && split_k == 1 &&
+                    ep->kind != DEVIT_EPI_DGELU_BF16 && ep->kind != DEVIT_EPI_ATOMIC_F32;
+#define DEVIT_LAUNCH_GEMM4(KIND_)                                                                              \
+  do {                                                                                                         \
+    constexpr int lds = (3 * 256 + 2 * 256) * 128;                                                             \
+    static bool attr = false;                                                                                  \
+    if (!attr) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm4_kernel<KIND_, false>,                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
+      DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
+      attr = true;                                                                                             \
+    }                                                                                                          \
+    hipLaunchKernelGGL((gemm4_kernel<KIND_, false>), dim3((unsigned)nwg), dim3(256), lds, s, g);               \
+  } while (0)
+  if (use4) {
+    switch (ep->kind) {
+      case DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_GEMM4(DEVIT_EPI_STORE_BF16); break;
+      case DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_GEMM4(DEVIT_EPI_STORE_F32); break;
+      case DEVIT_EPI_GELU_BF16: DEVIT_LAUNCH_GEMM4(DEVIT_EPI_GELU_BF16); break;
+      case DEVIT_EPI_RESIDUAL_F32: DEVIT_LAUNCH_GEMM4(DEVIT_EPI_RESIDUAL_F32); break;
+      case DEVIT_EPI_PATCH_F32: DEVIT_LAUNCH_GEMM4(DEVIT_EPI_PATCH_F32); break;
+      default: DEVIT_CHECK(false, DEVIT_ERR_ARG, "devit_gemm_bf16: epilogue %d has no four-wave instantiation", ep->kind);
+    }
+  } else if (cfg == 3) DEVIT_LAUNCH_GEMM(256, 256, 2, 4, 2);
   else DEVIT_LAUNCH_GEMM(128, 128, 2, 2, 2);
+#undef DEVIT_LAUNCH_GEMM4
 #undef DEVIT_LAUNCH_ONE
 #undef DEVIT_LAUNCH_ONE_T
 #undef DEVIT_LAUNCH_FWD16
