@@ -135,3 +135,12 @@ def test_integration_doc_stub_matches_binding():
         names = re.findall(r'\("(\w+)",', m.group(1))
         assert names == [f[0] for f in real._fields_], (cls, names)
     assert f"all {len(_lib.SIGNATURES)} symbols" in doc, "INTEGRATION.md quotes a stale symbol count"
+
+
+def test_gemm4_inc_is_current(tmp_path):
+    """csrc/gemm4_kloop.inc (the four-wave GEMM's K loop as inline asm) is GENERATED: tools/gen_gemm4.py must reproduce the
+    committed file byte for byte, so that the asm in the tree is the asm the documented generator emits."""
+    out = tmp_path / "gemm4_kloop.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GEMM4_")}      # (the experiment switches of the generator off)
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_gemm4.py"), str(out)], env=env)
+    assert out.read_bytes() == open(os.path.join(ROOT, "devit_amd", "csrc", "gemm4_kloop.inc"), "rb").read()

@@ -91,6 +91,36 @@ def test_gemm_persistent_schedule(dev, M, N, K, kind, mv):
     assert bool((out[lim:].float() == 3.0).all())
 
 
+@pytest.mark.parametrize("M,N,K,kind,mv", [
+    (12800, 2304, 768, 0, 0),        # bf16 store: 450 tiles, uneven shares, 12 K-steps per tile
+    (8192, 768, 1536, 2, 8000),      # fp32 residual with padding rows in the last m-tile (96 tiles)
+    (6400, 1536, 384, 1, 0),         # GELU + pre-activation, 6 K-steps per tile (the shortest loop the step has)
+    (16384, 256, 192, 1, 0),         # 3 K-steps: first / middle / last step each run exactly once per tile (64 tiles: the fewest that take 256x256 tiles)
+    (16384, 512, 768, 6, 0),         # fp32 store
+])
+def test_gemm_four_wave_kernel_bit_identical(dev, monkeypatch, M, N, K, kind, mv):
+    """The opt-in four-wave kernel (DEVIT_GEMM4=1: gemm4_kernel, K loop = generated inline asm, csrc/gemm4_kloop.inc) accumulates every
+    output element in the same order as the eight-wave kernel and runs the same epilogue code: outputs bit-identical, twice in a row
+    (the second launch starts with a warm ring / different slot phase)."""
+    from devit_amd import ops, _lib as L
+    a, w, bias = rnd((M, K), dev, dtype=BF16), rnd((N, K), dev, 0.05, 1, BF16), rnd((N,), dev, 0.1, 2)
+    res = rnd((M, N), dev, 1.0, 3) if kind == L.EPI_RESIDUAL_F32 else None
+    f32 = kind in (L.EPI_RESIDUAL_F32, L.EPI_STORE_F32)
+    outs = {}
+    for flag in ("0", "1", "1"):
+        monkeypatch.setenv("DEVIT_GEMM4", flag)
+        out = torch.full((M, N), 7.0, dtype=F32 if f32 else BF16, device=dev)
+        aux = torch.zeros((M, N), dtype=BF16, device=dev) if kind == L.EPI_GELU_BF16 else None
+        ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, bias=bias, res=res, aux=aux, m_valid=mv)
+        torch.cuda.synchronize()
+        outs.setdefault(flag, []).append((out, aux))
+    ref, ref_aux = outs["0"][0]
+    for out, aux in outs["1"]:
+        assert torch.equal(out, ref)
+        if aux is not None:
+            assert torch.equal(aux, ref_aux)
+
+
 def test_gemm_ragged_gelu_dgelu(dev):
     """N = 1152 (4.5 x 256: the compacted student's hidden width at shrink_ratio 0.3) through the 256x256 tile with a half-empty
     last n-tile, GELU (+ pre-activation, + gate) and dGELU epilogues."""
