@@ -154,3 +154,64 @@ def test_two_ranks_share_one_gpu():
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "ddp_two_ranks_one_gpu.json"), "w") as f:
         json.dump(res, f, indent=1)
+
+
+def test_exchange_through_torch_distributed_nccl_at_world_size_one():
+    """The DEFAULT transport at N > 1 -- torch.distributed's NCCL (= RCCL) process group, all_reduce(async_op=True) on the
+    exchange stream per bucket during backward -- exercised by a `-m gpu` test as far as one GPU allows (what
+    `bench.py --rehearse-exchange torch` does): a world-size-1 NCCL group, the reducer told it has two ranks.  Two real steps
+    (clip 1.0, AdamW, EMA) must leave the masters where a run WITHOUT the exchange leaves them when its optimizer is handed the
+    same 1 / world: RCCL at one rank moves no data, so any difference would be the exchange machinery (stream joins, bucket views,
+    grad_scale)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import devit_amd
+    from devit_amd import ddp, optim
+    dev = torch.device("cuda")
+    C, B = 250, 4                                         # config 4's class count
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.manual_seed(11)
+    img = torch.randn(B, 3, 224, 224, device=dev)
+    soft = torch.full((B, C), 0.1 / C, device=dev)
+    soft[:, 7] += 0.9
+    teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
+    for p in teacher.parameters():
+        p.requires_grad_(False)
+
+    def run(exchange):
+        torch.manual_seed(5)
+        student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.0).to(dev).train()
+        flat = ddp.FlatParams(student)
+        flat.attach_bf16(student)
+        red = ddp.BucketedGradReducer(flat, world=2 if exchange else None).attach(student)
+        opt = optim.FlatAdamW(flat, lr=1e-3, max_norm=1.0, ema_decay=0.99996)
+        orders = []
+        for _ in range(2):
+            opt.zero_grad()
+            _step(student, teacher, img, soft)
+            orders.append(red.finish())
+            if exchange:
+                assert flat.grad_scale == 0.5
+            else:
+                flat.grad_scale = 0.5                     # the same 1 / world, without the exchange
+            opt.step()
+        torch.cuda.synchronize()
+        return flat.flat.clone(), opt.ema.clone(), red, orders
+
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        m1, e1, red, orders = run(True)
+        assert red.world == 2 and len(red.buckets) >= 4 and red.comm is None       # torch.distributed transport, not the C-ABI one
+        assert all(o == list(range(len(red.buckets))) for o in orders)              # every bucket launched, in flat order
+    finally:
+        dist.destroy_process_group()
+    m0, e0, _, _ = run(False)
+    # same kernels, same inputs; the split-K weight gradients leave through fp32 atomics (summation order), AdamW amplifies
+    # nothing at lr 1e-3: masters agree to fp32 round-off of the gradients
+    assert float((m1 - m0).abs().max()) < 2e-6, float((m1 - m0).abs().max())
+    assert float((e1 - e0).abs().max()) <= 1e-9 + 1e-4 * float((m1 - m0).abs().max())
