@@ -118,23 +118,35 @@ def test_closed_loop_trajectory_vs_oracle(dev):
     # other way on that side, so the per-element bound is loose by construction and the trajectory is judged by the loss curve and
     # by the L2 distance of the MOVEMENT (final - initial) relative to the reference's movement.  Bars = ~2x measured (conftest.chk
     # records the values: profiles/*_parity_margins.json).
-    bars = {"f32": dict(loss=1e-4, mov=1e-3, maxabs=1e-3, ema=2e-7), "bf16": dict(loss=5e-3, mov=0.5, maxabs=2.5e-2, ema=1e-5)}
+    # loss bars: (total, cls) and (q, k, v) apart -- the three relation losses are small numbers (~1e-3 of the total) whose relative
+    # deviation grows with the step index as rounding-level differences of the weights pass through AdamW (5.8e-7 at step 1, 2.6e-4
+    # at step 10 on the exact-fp32 path); the total stays within 3e-5
+    # Bars ~2x measured on MI355X (round 4: f32 4.1e-5 / 2.6e-4 / 3.2e-5 / 1.1e-4; bf16 1.4e-2 / 6.5e-2 / 2.7e-2 / 7.2e-3).  The bf16
+    # numbers are what elementwise gradient normalisation does to bf16 gradient noise at lr 1e-3 without warm-up (step 1 is within
+    # 2e-4): the direction of the movement is right to 2.7 %.  EMA: on the matrices (|w| ~ 0.02) it must track the reference's to
+    # (1 - decay) x the parameter deviation; on the O(1) LayerNorm weights an fp32 EMA with decay 0.99996 carries ~1 ulp = 1.2e-7
+    # of rounding per step whichever way the update is written (the kernel's fma vs torch's two roundings).
+    bars = {"f32": dict(loss=1e-4, rel=1e-3, step1=1e-5, mov=1e-4, maxabs=3e-4, ema2d=1e-7, ema1d=2e-6),
+            "bf16": dict(loss=3e-2, rel=1.3e-1, step1=1e-3, mov=6e-2, maxabs=1.5e-2, ema2d=6e-6, ema1d=6e-6)}
+    ok = True
     for prec in ("f32", "bf16"):
         losses, final, ema, init, _, stale = res[prec]
         b = bars[prec]
         assert stale == 0.0, f"{prec}: bf16 weight copy differs from the re-cast masters by {stale}"
         e = np.abs(losses - ref_losses) / np.abs(ref_losses)
-        assert chk(float(e.max()), b["loss"]), (prec, "loss curve", e.max(axis=0))
         mov = torch.cat([(final[n] - init[n]).flatten() for n in ref_final])
         mov_rel = float((mov - ref_mov).norm() / ref_mov.norm())
         worst = float((mov - ref_mov).abs().max())
-        worst_ema = max(float((ema[n] - ref_ema[n]).abs().max()) for n in ref_final)
-        assert chk(mov_rel, b["mov"]), (prec, "movement, relative L2", mov_rel)
-        assert chk(worst, b["maxabs"]), (prec, "final parameters, max abs", worst)
-        assert chk(worst_ema, b["ema"]), (prec, "EMA", worst_ema)
+        ema2d = max(float((ema[n] - ref_ema[n]).abs().max()) for n in ref_final if ref_final[n].ndim >= 2)
+        ema1d = max(float((ema[n] - ref_ema[n]).abs().max()) for n in ref_final if ref_final[n].ndim < 2)
         moved = max(float((ema[n] - init[n]).abs().max()) for n in ema)
-        assert moved > 1e-8, moved                  # the EMA is not a frozen copy
-        print(f"{prec}: loss curve rel err {e.max():.2e}, movement rel L2 {mov_rel:.2e}, max abs {worst:.2e} (moved {drift:.2e}), EMA abs err {worst_ema:.2e}")
+        print(f"{prec}: loss curve rel err total/cls {e[:, :2].max():.2e} (step 1: {e[0, :2].max():.2e}) q/k/v {e[:, 2:].max():.2e}, "
+              f"movement rel L2 {mov_rel:.2e}, max abs {worst:.2e} (moved {drift:.2e}), EMA abs err matrices {ema2d:.2e} / vectors {ema1d:.2e} "
+              f"(moved {moved:.2e})")
+        ok &= chk(float(e[:, :2].max()), b["loss"]) and chk(float(e[:, 2:].max()), b["rel"]) and chk(float(e[0, :2].max()), b["step1"]) \
+            and chk(mov_rel, b["mov"]) and chk(worst, b["maxabs"]) and chk(ema2d, b["ema2d"]) and chk(ema1d, b["ema1d"]) \
+            and moved > 1e-8                                                                   # (the EMA is not a frozen copy)
+    assert ok
 
 
 def test_full_size_step_vs_oracle(dev):
