@@ -272,7 +272,10 @@ __device__ __forceinline__ void load_cols(const devit_epilogue& ep, int lane, in
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     noff[j] = nw + tile_row<BF16_OUT>(j, 4 * (lane >> 4));
-    bias[j] = ep.bias ? *(const f32x4*)(ep.bias + noff[j]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (the dGELU kind is a dgrad: no bias by contract, checked on the host -- 16 registers the 255-VGPR 256x256 instantiation
+    // does not have: it spilled 4 to scratch with them, and scratch reloads inside a K-step land in the counted vmcnt waits)
+    if constexpr (KIND == DEVIT_EPI_DGELU_BF16) bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    else bias[j] = ep.bias ? *(const f32x4*)(ep.bias + noff[j]) : (f32x4){0.f, 0.f, 0.f, 0.f};
     if (SCALED) cs[j] = ep.colscale ? *(const f32x4*)(ep.colscale + noff[j]) : (f32x4){1.f, 1.f, 1.f, 1.f};
   }
 }
@@ -283,7 +286,7 @@ __device__ __forceinline__ void settle_cols(f32x4 (&bias)[4], f32x4 (&cs)[4]) {
   constexpr bool SCALED = KIND == DEVIT_EPI_GELU_BF16 || KIND == DEVIT_EPI_DGELU_BF16;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    asm volatile("" : "+v"(bias[j]));
+    if (KIND != DEVIT_EPI_DGELU_BF16) asm volatile("" : "+v"(bias[j]));
     if (SCALED) asm volatile("" : "+v"(cs[j]));
   }
 }
@@ -1185,7 +1188,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
     DEVIT_CHECK(ep->pos && ep->patch_tokens > 0 && (ep->m_valid > 0 ? ep->m_valid : M) % ep->patch_tokens == 0 && batch == 1,
                 DEVIT_ERR_ARG,
                 "PATCH: pos / tokens");
-  if (ep->kind == DEVIT_EPI_DGELU_BF16) DEVIT_CHECK(ep->aux_in != nullptr, DEVIT_ERR_ARG, "DGELU: aux_in");
+  if (ep->kind == DEVIT_EPI_DGELU_BF16)
+    DEVIT_CHECK(ep->aux_in != nullptr && ep->bias == nullptr, DEVIT_ERR_ARG, "DGELU: needs aux_in, takes no bias (it is a dgrad)");
   if (ep->kind == DEVIT_EPI_ATOMIC_F32 && ep->aux)
     DEVIT_CHECK(batch == 1, DEVIT_ERR_ARG, "ATOMIC: the fused row sums of A (aux) need batch == 1");
   DEVIT_CHECK(ep->exact_gelu == 0, DEVIT_ERR_ARG, "devit_gemm_bf16: exact_gelu=1 (erff) is not built; the fused GELU is the "
@@ -1307,8 +1311,19 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
       case 1 * 16 + DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_STORE_BF16); break;        \
       case 1 * 16 + DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_STORE_F32); break;          \
       case 1 * 16 + DEVIT_EPI_DGELU_BF16: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, false, true, DEVIT_EPI_DGELU_BF16); break;        \
-      case 3 * 16 + DEVIT_EPI_ATOMIC_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, true, true, DEVIT_EPI_ATOMIC_F32); break;         \
-      case 3 * 16 + DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, true, true, DEVIT_EPI_STORE_F32); break;           \
+      case 3 * 16 + DEVIT_EPI_ATOMIC_F32:   /* k-major x k-major never takes the 256x256 tile (cfg 3 excludes variant 3): not */ \
+      case 3 * 16 + DEVIT_EPI_STORE_F32:    /* instantiated there (the 256x256 atomic kernel needed 257 registers: 1 spill)       */ \
+        if (int rc_ = [&](auto small) -> int {                                                                 \
+          if constexpr (decltype(small)::value) {                                                              \
+            if (ep->kind == DEVIT_EPI_ATOMIC_F32) DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, true, true, DEVIT_EPI_ATOMIC_F32);  \
+            else DEVIT_LAUNCH_ONE(BM_, BN_, WMM_, WNN_, NS_, true, true, DEVIT_EPI_STORE_F32);                  \
+            return 0;                                                                                          \
+          } else {                                                                                             \
+            devit_set_error("devit_gemm_bf16: k-major x k-major operands run on 128x128 tiles only");          \
+            return DEVIT_ERR_ARG;                                                                              \
+          }                                                                                                    \
+        }(std::integral_constant<bool, BM_ == 128>())) return rc_;                                             \
+        break;                                                                                                 \
       default:                                                                                                 \
         DEVIT_CHECK(false, DEVIT_ERR_ARG, "devit_gemm_bf16: layout %d with epilogue %d is not instantiated", variant, ep->kind); \
     }                                                                                                          \
