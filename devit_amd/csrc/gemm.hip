@@ -38,7 +38,7 @@ constexpr bool DMA_B_NT = true;
 constexpr bool DMA_B_NT = false;
 #endif
 #ifndef DEVIT_RAGGED_MIN_K
-#define DEVIT_RAGGED_MIN_K 768
+#define DEVIT_RAGGED_MIN_K 384   // plain-store launches take the 256x256 tile from this K on (round 4: student qkv, N 1152 K 384: 86 -> 70 us cold, 75 -> 70 in the step)
 #endif
 
 // n / d for 0 <= n < 2^31 by multiply-shift (Granlund-Montgomery round-up): three SALU ops instead of the
@@ -1225,7 +1225,9 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   // (also the GELU / dGELU epilogues: hidden 1152 = the compacted student's MLP width at shrink_ratio 0.3)
   const bool ragged_ok = ((variant == 0 && (light_epi || ep->kind == DEVIT_EPI_GELU_BF16)) ||
                           (variant == 1 && ep->kind == DEVIT_EPI_DGELU_BF16)) && N % 256 == 128 && N >= 1024;
-  if (M % 256 == 0 && (N % 256 == 0 || ragged_ok) && (K >= 1536 || (K >= DEVIT_RAGGED_MIN_K && light_epi) || gelu_epi) && variant != 3) cfg = 3;
+  // (the patch-embedding launch of a 768-wide model: 124 -> 108 us in the step on the larger tile; at N = 384 the 128x128 tile stays)
+  const bool patch_wide = ep->kind == DEVIT_EPI_PATCH_F32 && K >= 768 && N % 256 == 0;
+  if (M % 256 == 0 && (N % 256 == 0 || ragged_ok) && (K >= 1536 || (K >= DEVIT_RAGGED_MIN_K && light_epi) || gelu_epi || patch_wide) && variant != 3) cfg = 3;
   // too few 256x256 tiles to give every CU one (the token-row GEMMs of the lean last block, M = 512): 128x128 tiles
   // quarter the time of the longest workgroup; same accumulation order per output element either way
   if (cfg == 3 && (long long)(M / 256) * ((N + 255) / 256) * batch < 64) cfg = 1;
@@ -1329,12 +1331,16 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
     }                                                                                                          \
   } while (0)
   // the four-wave kernel takes the 256x256 launches it is built for: row-major x row-major, whole 256-wide n-tiles, bf16
-  // OPT-IN (DEVIT_GEMM4=1, read per call so that a test can switch it): measured at parity with the eight-wave kernel -- both
-  // run their K-step at ~2600-2700 cycles, the rate at which a CU's LDS-DMA requests are served under full-chip load
-  // (profiles/r04_a_gemm_four_wave.txt)
+  // Which 256x256 launches take it (round 4, per-shape times inside the serialized step, tools/step_gemm_table.py): the two kernels
+  // run their K loops at the same fill-bound rate (profiles/r04_a_gemm_four_wave.txt); the four-wave one is 2.5-3.4 % faster where the
+  // epilogue is a plain bf16 store or the fp32 residual at K >= 768 (teacher qkv 172.6 -> 168.3 us, fc2 266 -> 257), and 5-10 % SLOWER
+  // with the GELU epilogue (one wave per SIMD issues its vector instructions at half the rate two waves share) and on the batched
+  // Gram launches.  DEVIT_GEMM4=0 / 1 forces it off / on for everything it is built for (read per call: tests switch it).
   const char* gemm4_env = getenv("DEVIT_GEMM4");
-  const bool use4 = gemm4_env && atoi(gemm4_env) != 0 && cfg == 3 && variant == 0 && !f16 && N % 256 == 0 && K / BK >= 3 && split_k == 1 &&
-                    ep->kind != DEVIT_EPI_DGELU_BF16 && ep->kind != DEVIT_EPI_ATOMIC_F32;
+  const bool gemm4_ok = cfg == 3 && variant == 0 && !f16 && N % 256 == 0 && K / BK >= 3 && split_k == 1 &&
+                        ep->kind != DEVIT_EPI_DGELU_BF16 && ep->kind != DEVIT_EPI_ATOMIC_F32;
+  const bool gemm4_pays = (ep->kind == DEVIT_EPI_STORE_BF16 || ep->kind == DEVIT_EPI_RESIDUAL_F32) && K >= 768 && batch == 1;
+  const bool use4 = gemm4_ok && (gemm4_env ? atoi(gemm4_env) != 0 : gemm4_pays);
 #define DEVIT_LAUNCH_GEMM4(KIND_)                                                                              \
   do {                                                                                                         \
     constexpr int lds = (3 * 256 + 2 * 256) * 128;                                                             \

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Per-shape GEMM times INSIDE the serialized DEKD step (the cache state the launches really run in), for the tile / kernel selection of
+the environment (DEVIT_GEMM_FORCE=0/1/3, DEVIT_GEMM4=0/1): every GEMM launch of three instrumented steps bracketed by events, averaged per
+(layout, kind, M, N, K, batch, split_k).  One process per setting (the switches are read once); compare the printed tables."""
+import os, sys, collections
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+os.environ["DEVIT_TEACHER_STREAM"] = "0"
+import devit_amd
+from devit_amd import ddp, engine, losses, ops, optim
+
+dev = torch.device("cuda"); B, C = 256, 25
+torch.manual_seed(0)
+student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None).to(dev).train()
+torch.manual_seed(1)
+teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
+for p in teacher.parameters():
+    p.requires_grad_(False)
+flat = ddp.FlatParams(student); flat.attach_bf16(student)
+if float(os.environ.get("SHRINK", "0")) > 0:
+    from devit_amd import shrink
+    r = float(os.environ["SHRINK"]); gen = torch.Generator().manual_seed(7)
+    for blk in student.blocks:
+        hm, nm = torch.ones(6), torch.ones(1536)
+        hm[torch.randperm(6, generator=gen)[: 6 - int(6 * (1 - r))]] = 0
+        nm[torch.randperm(1536, generator=gen)[: 1536 - int(1536 * (1 - r))]] = 0
+        blk.attn.gate, blk.mlp.gate = hm, nm
+    shrink.compact(student, trainable=True)
+reducer = ddp.BucketedGradReducer(flat).attach(student)
+opt = optim.FlatAdamW(flat, lr=5e-4 * B / 512.0, weight_decay=0.0, max_norm=1.0, ema_decay=0.99996)
+criterion = losses.DistillLoss(losses.SoftTargetCrossEntropy(), "hard", 0.5, 1.0)
+g = torch.Generator(device=dev).manual_seed(1234)
+img = torch.randn((B, 3, 224, 224), generator=g, device=dev)
+y = torch.randint(0, C, (B,), generator=g, device=dev)
+soft = torch.full((B, C), 0.1 / C, device=dev).scatter_(1, y[:, None], 0.9 + 0.1 / C)
+
+def step():
+    opt.zero_grad()
+    out = engine.distill_forward(student, teacher, img, soft, gama=(0.2, 0.1, 0.3), criterion=criterion)
+    out["loss"].backward()
+    reducer.finish(); opt.step()
+
+recs = []
+real = ops.gemm
+def traced(a, lda, a_km, b, ldb, b_km, M, N, K, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); real(a, lda, a_km, b, ldb, b_km, M, N, K, **kw); e1.record()
+    recs.append((("km" if a_km else "row") + "x" + ("km" if b_km else "row"), kw.get("kind"), M, N, K, kw.get("batch", 1), kw.get("split_k", 1), e0, e1))
+for _ in range(3): step()
+torch.cuda.synchronize()
+ops.PROFILE = []            # (switches the host path to single-kernel calls, as bench.py's instrumented step does)
+ops.gemm = traced
+STEPS = 3
+for _ in range(STEPS): step()
+torch.cuda.synchronize()
+ops.gemm = real; ops.PROFILE = None
+agg = collections.OrderedDict()
+for lay, kind, M, N, K, batch, sk, e0, e1 in recs:
+    d = agg.setdefault((lay, kind, M, N, K, batch, sk), [0.0, 0])
+    d[0] += e0.elapsed_time(e1) * 1e3; d[1] += 1
+tag = f"FORCE={os.environ.get('DEVIT_GEMM_FORCE', '0')} GEMM4={os.environ.get('DEVIT_GEMM4', '0')}"
+tot = 0.0
+KIND = {0: "store16", 1: "gelu", 2: "resid", 3: "patch", 4: "dgelu", 5: "atomic", 6: "store32"}
+for (lay, kind, M, N, K, batch, sk), (us, n) in agg.items():
+    tot += us / STEPS
+    print(f"{tag} {lay:8s} {KIND.get(kind, kind):8s} M={M:6d} N={N:5d} K={K:6d} b={batch:3d} sk={sk:3d}  x{n // STEPS:3d}/step  {us / n:8.1f} us  {2.0 * M * N * K * batch / (us / n) / 1e6:7.1f} TF")
+print(f"{tag} total GEMM ms per step {tot / 1e3:.3f}")
