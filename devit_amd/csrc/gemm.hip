@@ -1217,6 +1217,7 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   // epilogue at K <= 768 stays on 128x128 (teacher proj 458 vs 442), as does everything whose N is not a multiple
   // of 256 and the split-K wgrads.  (A 256x128 tile with a 3-deep ring and a 128x128 tile with a 3-deep ring at one
   // workgroup per CU were built and lost on every shape, warm and cold; they are gone.)
+  const bool f16_in = ep->dtype16 != 0;       // (f16 operands run the eight-wave kernels only)
   const bool light_epi = ep->kind == DEVIT_EPI_STORE_BF16 || ep->kind == DEVIT_EPI_STORE_F32;
   const bool gelu_epi = ep->kind == DEVIT_EPI_GELU_BF16 || ep->kind == DEVIT_EPI_DGELU_BF16;
   int cfg = 1;
@@ -1227,7 +1228,9 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
                           (variant == 1 && ep->kind == DEVIT_EPI_DGELU_BF16)) && N % 256 == 128 && N >= 1024;
   // (the patch-embedding launch of a 768-wide model: 124 -> 108 us in the step on the larger tile; at N = 384 the 128x128 tile stays)
   const bool patch_wide = ep->kind == DEVIT_EPI_PATCH_F32 && K >= 768 && N % 256 == 0;
-  if (M % 256 == 0 && (N % 256 == 0 || ragged_ok) && (K >= 1536 || (K >= DEVIT_RAGGED_MIN_K && light_epi) || gelu_epi || patch_wide) && variant != 3) cfg = 3;
+  // (the fp32 residual epilogue at K = 768, teacher proj: 125.9 us on 128x128 tiles, 120.3 on the four-wave 256x256 kernel, in the step)
+  const bool resid_wide = ep->kind == DEVIT_EPI_RESIDUAL_F32 && K >= 768 && N % 256 == 0 && variant == 0 && !f16_in;
+  if (M % 256 == 0 && (N % 256 == 0 || ragged_ok) && (K >= 1536 || (K >= DEVIT_RAGGED_MIN_K && light_epi) || gelu_epi || patch_wide || resid_wide) && variant != 3) cfg = 3;
   // too few 256x256 tiles to give every CU one (the token-row GEMMs of the lean last block, M = 512): 128x128 tiles
   // quarter the time of the longest workgroup; same accumulation order per output element either way
   if (cfg == 3 && (long long)(M / 256) * ((N + 255) / 256) * batch < 64) cfg = 1;
