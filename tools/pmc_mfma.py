@@ -11,8 +11,8 @@ import collections, csv, glob, json, os, re, sys
 
 def main():
     d, out = sys.argv[1:3]
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-    assert f, f"no counter_collection.csv under {d}"
+    f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+    assert f, f"no counter_collection.csv under {d}"      # (newest first: a merged gpurun_out/ keeps earlier calls' files)
     tot = collections.defaultdict(collections.Counter)
     disp = collections.defaultdict(set)
     for r in csv.DictReader(open(f[0])):
@@ -30,7 +30,10 @@ def main():
                    "wait_any_frac": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
                    "wait_inst_frac": c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
                    "active_inst_frac": c["SQ_ACTIVE_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0)}
-    dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+(, (true|false))?>", k)]   # (+ F16)
+    # the bench's dominant template: every gemm_kernel<.., A_KM=false, B_KM=false, ..> instantiation and the four-wave kernel
+    # (gemm4_kernel<KIND, F16>: row-major x row-major by construction)
+    dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+(, (true|false))?>", k)
+           or re.search(r"gemm4_kernel<\d+, (true|false)>", k)]
     assert dom, "no gemm_kernel<.., A_KM=false, B_KM=false, ..> dispatch found: the kernel-name pattern is stale"
     busy = sum(tot[k]["SQ_VALU_MFMA_BUSY_CYCLES"] for k in dom)
     act = sum(tot[k]["GRBM_GUI_ACTIVE"] for k in dom) / 8.0 * 1024.0
@@ -39,7 +42,7 @@ def main():
     res = {"kernel_sources_hash": bench.kernel_sources_hash(), "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
                      "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace over bench.py --steps 2 --warmup 1 "
                      "--teacher-lookahead 0 (one launch at a time)",
-           "dominant_template": "gemm_kernel<*, A_row, B_row, *>", "mfma_busy": round(busy / max(act, 1.0), 4),
+           "dominant_template": "gemm_kernel<*, A_row, B_row, *> + gemm4_kernel<*>", "mfma_busy": round(busy / max(act, 1.0), 4),
            "kernels": {k[:120]: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                        for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["gui_active_cycles_per_launch"] * kv[1]["launches"])[:24]}}
     json.dump(res, open(out, "w"), indent=1)

@@ -11,8 +11,8 @@ import collections, csv, glob, json, os, re, sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-    assert f, f"no counter_collection.csv under {d}"
+    f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+    assert f, f"no counter_collection.csv under {d}"      # (newest first: a merged gpurun_out/ keeps earlier calls' files)
     tot, cnt = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] != counter:
@@ -32,8 +32,10 @@ def main():
         rows[k] = {"launches": int(max(fc[k], wc[k])),
                    "fetch_bytes_per_launch": ft[k] / max(fc[k], 1) * 1024 * 2,      # KiB -> B, x2 (gfx950)
                    "write_bytes_per_launch": wt[k] / max(wc[k], 1) * 1024}
-    # the bench's dominant template: every gemm_kernel<.., A_KM=false, B_KM=false, ..> instantiation
-    dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+(, (true|false))?>", k)]   # (+ F16)
+    # the bench's dominant template: every gemm_kernel<.., A_KM=false, B_KM=false, ..> instantiation and the four-wave kernel
+    # (gemm4_kernel<KIND, F16>: row-major x row-major by construction)
+    dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+(, (true|false))?>", k)
+           or re.search(r"gemm4_kernel<\d+, (true|false)>", k)]
     assert dom, "no gemm_kernel<.., A_KM=false, B_KM=false, ..> dispatch found: the kernel-name pattern is stale"
     n = sum(rows[k]["launches"] for k in dom)
     fetch = sum(rows[k]["fetch_bytes_per_launch"] * rows[k]["launches"] for k in dom) / max(n, 1)
@@ -42,7 +44,7 @@ def main():
     import bench                   # kernel_sources_hash(): which kernel sources this summary was taken on
     res = {"kernel_sources_hash": bench.kernel_sources_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 "
                      "--teacher-lookahead 0; FETCH_SIZE x2 (gfx950 128-B requests counted as 64 B); Infinity-Cache hits included",
-           "dominant_template": "gemm_kernel<*, A_row, B_row, *>", "launches": n,
+           "dominant_template": "gemm_kernel<*, A_row, B_row, *> + gemm4_kernel<*>", "launches": n,
            "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
            "traffic_bytes_per_launch": round(fetch + write),
            "kernels": {k[:120]: {kk: (round(vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
