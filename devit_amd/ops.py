@@ -294,9 +294,12 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
     x2o = torch.empty((B, N, D), dtype=F32, device=dev)
     linear_fwd(h, bp.fc2_w16, bp.fc2_b, M, out=x2o.view(M, D), kind=L.EPI_RESIDUAL_F32, res=x1.view(M, D), rowscale=dp2,
                rows_per_scale=N, dtype16=t16)
-    if bp.module is not None:  # shrink contract (core/imp_rank.py:31,108): post-mask values
+    if bp.module is not None and not cfg.lean_tokens:  # shrink contract (core/imp_rank.py:31,108): post-mask values
         bp.module.mlp.neuron_output = h[:M].view(B, N, Hd)
         bp.module.attn.head_output = attn_o[:M].view(B, N, H, Da // H)
+    elif bp.module is not None:     # (inside de_vit.lean_tail: not handed out, see _encoder_forward_c)
+        bp.module.mlp.neuron_output = None
+        bp.module.attn.head_output = None
     if need_grad:
         s = dict(x=x, ln1=ln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn_o=attn_o, lse=lse, x1=x1, ln2=ln2, mean2=mean2,
                  rstd2=rstd2, h=h, h_pre=h_pre, dp1=dp1, dp2=dp2)
@@ -599,9 +602,19 @@ def _encoder_forward_composite(x, cfg, need_grad, nb):
                  att=view(L.ACT_ATT, M, D, BF16) if cfg.want_att else None)
         v["qkv"]._devit_arena = True          # a view of an arena from ARENA_ALLOC_STREAM's pool (engine._hand_over)
         views.append(v)
-        if bp.module is not None:  # shrink contract (core/imp_rank.py:31,108): post-mask values
+        if bp.module is not None and not cfg.lean_tokens:  # shrink contract (core/imp_rank.py:31,108): post-mask values
             bp.module.mlp.neuron_output = view(L.ACT_H, mp, Hd, BF16)[:M].view(B, N, Hd)
             bp.module.attn.head_output = view(L.ACT_ATTN_O, mp, Da, BF16)[:M].view(B, N, bp.num_heads, Da // bp.num_heads)
+        elif bp.module is not None:
+            # inside de_vit.lean_tail the caller has declared that it reads the logits (and the middle block's q / k / v) only: the
+            # debug views are not handed out, and the ones an earlier public forward left are dropped, so a ranking pass run inside
+            # lean_tail fails loudly instead of reading stale values.  (This does NOT shrink the 35 GB peak: the per-layer q / k / v
+            # views of the returned dict hold the arenas too, and those must stay until the consumer stream has read them -- the
+            # arenas of a side-stream forward live in the CONSUMER's pool (ARENA_ALLOC_STREAM); dropping the unread layers' views
+            # at once hands their memory to the main stream while the teacher's kernels still write it: measured as a non-finite
+            # loss in the two-stream bench, round 4.)
+            bp.module.mlp.neuron_output = None
+            bp.module.attn.head_output = None
     run.views = views
     call("devit_encoder_fwd", nb, weights, acts, B, N, D, cfg.eps, stream_ptr())
     return run
