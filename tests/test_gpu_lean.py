@@ -199,3 +199,87 @@ def test_lean_tail_step_equals_full_step_bs256(dev):
     full = _step(s, t, img, soft, dps, lean=False)
     lean = _step(s, t, img, soft, dps, lean=True)
     print("bs 256 lean vs full: worst gradient", _compare_steps(full, lean, "bs256", exact_losses=False))
+
+
+def test_teacher_lookahead_two_streams_equals_in_step_teacher(dev):
+    """engine.TeacherLookahead (the bench's and train_1epoch_qkv's default): the frozen teacher's forward for batch k + 1 runs on a side
+    stream beside the student's step of batch k, its activation arenas living in the CONSUMER stream's allocator pool.  Five steps
+    over three alternating batches at bs 128 (big enough for the two streams to overlap for real, with optimizer steps in between so
+    that the main stream allocates and frees while the teacher runs): the teacher's logits must be bit-identical to the in-step,
+    one-stream teacher on every step, and every loss must be finite and equal to the one-stream run's up to the atomics'
+    summation order.  (Round 4: releasing a side-stream forward's unread arenas early passed every other test and produced a
+    non-finite loss only in bench.py; whether that corrupts anything is a matter of timing and of which blocks the allocator hands
+    out -- these runs passed with the faulty change too -- so the rule is ALSO asserted structurally at the end.)"""
+    import os
+    import devit_amd
+    from devit_amd import ddp, engine, optim
+    C, B = 25, 256
+    g = torch.Generator(device=dev).manual_seed(77)
+    batches = [torch.randn((B, 3, 224, 224), generator=g, device=dev) for _ in range(3)]
+    soft = torch.full((B, C), 0.1 / C, device=dev)
+    soft[:, 5] += 0.9
+    torch.manual_seed(2)
+    teacher = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C).to(dev).eval()
+    for p in teacher.parameters():
+        p.requires_grad_(False)
+
+    from devit_amd import ops
+    arena_bytes = ops._act_sizes(B, 198, 768, 768, 3072, 0)[2]        # one teacher block's activation arena (no save, no pad)
+
+    def run(lookahead):
+        torch.manual_seed(3)
+        student = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.0).to(dev).train()
+        flat = ddp.FlatParams(student)
+        flat.attach_bf16(student)
+        red = ddp.BucketedGradReducer(flat).attach(student)
+        opt = optim.FlatAdamW(flat, lr=1e-4, max_norm=1.0, ema_decay=0.99996)
+        look = engine.TeacherLookahead(teacher) if lookahead else None
+        if look is not None:
+            look.submit(batches[0])
+        logits, losses = [], []
+        for k in range(5):
+            x = batches[k % 3]
+            t_out = None
+            if look is not None:
+                t_out = look.take(x)
+                look.submit(batches[(k + 1) % 3])
+                # poison: whatever the allocator considers free on the main stream right now is overwritten with NaN while the
+                # teacher's kernels run on the side stream -- an arena released before its stream has finished with it does not survive
+                junk = [torch.full((arena_bytes // 4,), float("nan"), device=dev) for _ in range(16)]
+                del junk
+            opt.zero_grad()
+            out = engine.distill_forward(student, teacher, x, soft, teacher_outputs=t_out)
+            out["loss"].backward()
+            red.finish()
+            opt.step()
+            logits.append(out["teacher_logits"].detach().clone())
+            losses.append(out["loss"].detach().clone())
+        if look is not None:
+            look.take(batches[5 % 3])
+        torch.cuda.synchronize()
+        return logits, [float(v) for v in losses]
+
+    prev = os.environ.get("DEVIT_TEACHER_STREAM")
+    try:
+        os.environ["DEVIT_TEACHER_STREAM"] = "0"
+        ref_logits, ref_losses = run(False)
+        os.environ["DEVIT_TEACHER_STREAM"] = "1"
+        logits, losses = run(True)
+    finally:
+        if prev is None:
+            os.environ.pop("DEVIT_TEACHER_STREAM", None)
+        else:
+            os.environ["DEVIT_TEACHER_STREAM"] = prev
+    # The lifetime rule itself (timing decides whether breaking it corrupts anything, so the runs above can pass by luck): a
+    # side-stream forward's block arenas come from the CONSUMER stream's pool and are ordered by wait_stream() only, so every one
+    # of them must stay referenced by the returned dict until the consumer has joined -- all eleven body blocks' q / k / v views are
+    # handed out, tagged as arena views (the last block ran on its token rows: None).
+    main = torch.cuda.current_stream()
+    side = engine._side_stream.setdefault(dev.index or 0, torch.cuda.Stream())
+    out = engine._side_forward(teacher, batches[0], main, side)
+    main.wait_stream(side)
+    assert [q is not None for q in out["qkv"]] == [True] * 11 + [False]
+    assert all(getattr(getattr(q[0], "_devit_packed", (q[0],))[0], "_devit_arena", False) for q in out["qkv"][:11])
+    for k in range(5):
+        assert torch.equal(logits[k], ref_logits[k]), f"teacher logits of step {k} differ between the two-stream and the one-stream run"
+        assert losses[k] == losses[k] and abs(losses[k] - ref_losses[k]) <= 2e-3 * abs(ref_losses[k]), (k, losses[k], ref_losses[k])
