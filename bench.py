@@ -442,6 +442,7 @@ def main():
                       "launches_per_step": len(sel)}
     # (b) one launch at a time (`achieved` below): the kernel's own rate
     os.environ["DEVIT_TEACHER_STREAM"] = "0"      # serialise the two forwards so that event brackets time ONE kernel
+    os.environ["DEVIT_WGRAD_STREAM"] = "0"        # ... and the weight gradients back on the launch stream (csrc/encoder.hip)
     if feed is not None:
         assert next(feed, None) is None       # the prefetcher is drained (its last batch submits no look-ahead)
         feed = None

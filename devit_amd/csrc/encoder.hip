@@ -1,6 +1,8 @@
 // Whole encoder blocks per host call (devit_encoder_fwd / devit_block_bwd): the block's kernels are enqueued here, in C++,
 // through the same single-kernel entry points the granular path uses -- identical kernels, arguments and order, so the
-// two paths agree bit for bit (tests/test_gpu_kernels.py::test_block_calls_match_granular_path).  Host code only.
+// two paths agree bit for bit (tests/test_gpu_model.py::test_block_calls_match_granular_path; the weight gradients are
+// split-K atomics either way).  devit_block_bwd puts its four weight-gradient launches on a side stream of its own and joins
+// it before it returns (round 4, see there).  Host code only.
 #include "devit_common.h"
 
 namespace {
@@ -64,6 +66,31 @@ int linear_wgrad(const Ctx& c, const void* dy, const void* x, float* w_grad, flo
     int rc__ = (x);            \
     if (rc__ != DEVIT_OK) return rc__; \
   } while (0)
+
+// devit_block_bwd's side stream for the weight-gradient launches: one per device, created at first use, never destroyed
+struct WgradSide {
+  hipStream_t stream;
+  hipEvent_t ev[5];
+};
+int wgrad_side(WgradSide** out) {
+  const char* env = getenv("DEVIT_WGRAD_STREAM");      // (read per call: tests switch it)
+  const bool on = !(env && atoi(env) == 0);
+  static WgradSide per_dev[16];
+  static bool made[16] = {};
+  *out = nullptr;
+  if (!on) return DEVIT_OK;
+  int dev = 0;
+  DEVIT_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, DEVIT_ERR_DEVICE, "devit_block_bwd: hipGetDevice");
+  if (!made[dev]) {
+    DEVIT_CHECK(hipStreamCreateWithFlags(&per_dev[dev].stream, hipStreamNonBlocking) == hipSuccess, DEVIT_ERR_DEVICE,
+                "devit_block_bwd: cannot create the weight-gradient stream");
+    for (auto& e : per_dev[dev].ev)
+      DEVIT_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, DEVIT_ERR_DEVICE, "devit_block_bwd: cannot create an event");
+    made[dev] = true;
+  }
+  *out = &per_dev[dev];
+  return DEVIT_OK;
+}
 
 int check_dims(int B, int N, int D, int Da, int Hd) {
   DEVIT_CHECK(B > 0 && N > 0 && N <= 208 && D > 0 && D % 128 == 0 && Da > 0 && Da % 128 == 0 && Hd > 0 && Hd % 128 == 0,
@@ -197,6 +224,21 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
   DEVIT_CHECK(g.n1w && g.n1b && g.qkv_w && g.qkv_b && g.proj_w && g.proj_b && g.n2w && g.n2b && g.fc1_w && g.fc1_b &&
                   g.fc2_w && g.fc2_b, DEVIT_ERR_ARG, "devit_block_bwd: null gradient accumulator");
   Ctx c{B * N, pad_rows(B * N), B, N, D, eps, stream};
+  // The four weight-gradient launches go to a side stream of the library's own, each behind an event of the kernel that produces
+  // its operand; `stream` waits for them before this call returns its last kernel's successor (so callers see ONE stream, as
+  // before).  They depend on nothing downstream, and beside the dgrad chain their workgroups fill its kernels' partial last
+  // rounds (the N = 384 dgrads run 2.32 rounds of 512 workgroups): 10233 -> 10323 img/s, three interleaved pairs on one box
+  // (profiles/r04_h_wgrad_side_stream_ab.txt).  DEVIT_WGRAD_STREAM=0 keeps them on `stream`.
+  WgradSide* sd = nullptr;
+  TRY(wgrad_side(&sd));
+  Ctx cs = c;
+  auto fork = [&](int i) -> int {
+    if (!sd) return DEVIT_OK;
+    DEVIT_CHECK(hipEventRecord(sd->ev[i], (hipStream_t)stream) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->ev[i], 0) == hipSuccess,
+                DEVIT_ERR_LAUNCH, "devit_block_bwd: cannot fork the weight-gradient stream");
+    cs.stream = sd->stream;
+    return DEVIT_OK;
+  };
   void* const* b = a.buf;
   void* dh_pre = io->ws[DEVIT_BWD_DH_PRE];
   void* dln2 = io->ws[DEVIT_BWD_DLN2];
@@ -214,7 +256,8 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
   TRY(zero_pad(c, io->g_prev, D, 2));
   // ---- MLP branch: x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2))).  The weight gradient that only needs g2 first, then
   // dh_pre's producer and its consumers back to back (dh_pre is 156 MB at B = 256: keep it in the Infinity Cache)
-  TRY(linear_wgrad(c, io->g2, b[DEVIT_ACT_H], g.fc2_w, io->g2_bias_done ? nullptr : g.fc2_b, D, Hd));
+  TRY(fork(0));
+  TRY(linear_wgrad(cs, io->g2, b[DEVIT_ACT_H], g.fc2_w, io->g2_bias_done ? nullptr : g.fc2_b, D, Hd));
   {
     devit_epilogue ep = make_ep(DEVIT_EPI_DGELU_BF16, dh_pre, Hd, c.M);
     ep.colscale = w.neuron_gate;
@@ -222,21 +265,27 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
     TRY(linear_dgrad(c, io->g2, w.fc2_w16, D, Hd, ep));
   }
   TRY(linear_dgrad(c, dh_pre, w.fc1_w16, Hd, D, make_ep(DEVIT_EPI_STORE_BF16, dln2, D, c.M)));
-  TRY(linear_wgrad(c, dh_pre, b[DEVIT_ACT_LN2], g.fc1_w, g.fc1_b, Hd, D));
+  TRY(fork(1));
+  TRY(linear_wgrad(cs, dh_pre, b[DEVIT_ACT_LN2], g.fc1_w, g.fc1_b, Hd, D));
   // LN2 backward: dx1 = dx + LN'(dln2); g1 = bf16(dp1 * dx1); its column sums = the proj bias gradient
   TRY(devit_layernorm_bwd(dln2, 0, (const float*)b[DEVIT_ACT_X1], c.M, D, 0, 0, (const float*)b[DEVIT_ACT_MEAN2],
                           (const float*)b[DEVIT_ACT_RSTD2], w.n2w, io->dx, dx1, g1, a.dp1, N, g.n2w, g.n2b, g.proj_b, 1,
                           io->ws[DEVIT_BWD_LNWS], io->lnws_bytes, stream));
   // ---- attention branch: x1 = x + dp1 * proj(gate * attn(qkv(ln1)))
   TRY(linear_dgrad(c, g1, w.proj_w16, D, Da, make_ep(DEVIT_EPI_STORE_BF16, dattn, Da, c.M)));
-  TRY(linear_wgrad(c, g1, b[DEVIT_ACT_ATTN_O], g.proj_w, nullptr, D, Da));
+  TRY(fork(2));
+  TRY(linear_wgrad(cs, g1, b[DEVIT_ACT_ATTN_O], g.proj_w, nullptr, D, Da));
   TRY(devit_attn_bwd(b[DEVIT_ACT_QKV], b[DEVIT_ACT_ATTN_O], dattn, (const float*)b[DEVIT_ACT_LSE], w.head_gate, io->dqkv_add,
                      dqkv, B, N, H, 64, 0.125f, stream));
   TRY(linear_dgrad(c, dqkv, w.qkv_w16, 3 * Da, D, make_ep(DEVIT_EPI_STORE_BF16, dln1, D, c.M)));
-  TRY(linear_wgrad(c, dqkv, b[DEVIT_ACT_LN1], g.qkv_w, g.qkv_b, 3 * Da, D));
+  TRY(fork(3));
+  TRY(linear_wgrad(cs, dqkv, b[DEVIT_ACT_LN1], g.qkv_w, g.qkv_b, 3 * Da, D));
   // LN1 backward: dx_in = dx1 + LN'(dln1); g_prev = bf16(prev_dp2 * dx_in) (+ the block below's fc2 bias gradient)
   TRY(devit_layernorm_bwd(dln1, 0, a.x, c.M, D, 0, 0, (const float*)b[DEVIT_ACT_MEAN1], (const float*)b[DEVIT_ACT_RSTD1],
                           w.n1w, dx1, io->dx_in, io->g_prev, io->prev_dp2, N, g.n1w, g.n1b,
                           io->g_prev ? io->prev_fc2_b_grad : nullptr, 1, io->ws[DEVIT_BWD_LNWS], io->lnws_bytes, stream));
+  if (sd)
+    DEVIT_CHECK(hipEventRecord(sd->ev[4], sd->stream) == hipSuccess && hipStreamWaitEvent((hipStream_t)stream, sd->ev[4], 0) == hipSuccess,
+                DEVIT_ERR_LAUNCH, "devit_block_bwd: cannot join the weight-gradient stream");
   return DEVIT_OK;
 }

@@ -635,6 +635,49 @@ def test_block_calls_match_granular_path(models, dev, bs):
         assert chk(rel(g1[n], g0[n].cpu().numpy()), 2e-5), n          # split-K atomics: summation order only
 
 
+def test_weight_gradients_on_the_side_stream(models, dev, monkeypatch):
+    """devit_block_bwd runs its four weight-gradient launches on a side stream of its own behind events of their producers and joins
+    it before returning (csrc/encoder.hip).  Against DEVIT_WGRAD_STREAM=0 (everything on the caller's stream): loss and logits
+    bit-identical, every parameter's gradient to the order of their fp32 atomics -- with every transient buffer of the caching
+    allocator poisoned between the two runs, so that a weight-gradient launch that ran after its operands were recycled (a missing
+    join) or before they were written (a missing event) would read NaNs."""
+    from devit_amd import engine
+    s, t, _, _ = models
+    bs = 8
+    img = torch.from_numpy(det_array("img8", (8, 3, 224, 224)))[:bs].to(dev)
+    soft = torch.softmax(torch.from_numpy(det_array("comp_soft", (bs, C), std=2.0)), 1).to(dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    dps = []
+    for i in range(12):
+        keep = 1.0 - 0.1 * i / 11
+        sc = torch.floor(keep + torch.rand((2, bs), generator=g, device=dev)) / keep
+        dps.append((sc[0].contiguous(), sc[1].contiguous()))
+    res = {}
+    s.train()
+    try:
+        for flag in ("0", "1", "1"):
+            monkeypatch.setenv("DEVIT_WGRAD_STREAM", flag)
+            junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << 24, 1 << 22, 1 << 20, 1 << 20)]
+            del junk                                   # cached blocks the next run's transient buffers are carved from
+            for p in s.parameters():
+                p.grad = None
+            x = img.clone().requires_grad_(True)
+            out = engine.distill_forward(s, t, x, soft, dp_scales=dps)
+            out["loss"].backward()
+            res.setdefault(flag, []).append((out["loss"].detach().clone(), out["logits"][0].detach().clone(),
+                                             {n: p.grad.detach().clone() for n, p in s.named_parameters()}))
+        torch.cuda.synchronize()
+    finally:
+        for p in s.parameters():
+            p.grad = None
+    l0, lo0, g0 = res["0"][0]
+    for l1, lo1, g1 in res["1"]:
+        assert torch.equal(l0, l1) and torch.equal(lo0, lo1)
+        for n in g0:
+            assert bool(torch.isfinite(g1[n]).all()), n
+            assert chk(rel(g1[n], g0[n].cpu().numpy()), 2e-5), n
+
+
 # ------------------------------------------------------------------------------------------ DeiT criterion of train_subdata.py
 def test_distillation_loss_vs_golden(golden, dev):
     """losses.DistillationLoss against the reference's own class (utils/losses.py:44-119, teacher inside the criterion)
