@@ -37,7 +37,7 @@ BWD_DH_PRE, BWD_DLN2, BWD_DX1, BWD_G1, BWD_DATTN, BWD_DQKV, BWD_DLN1, BWD_LNWS, 
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("n1w", "n1b", "qkv_b", "proj_b", "n2w", "n2b", "fc1_b", "fc2_b", "qkv_w16",
                                           "proj_w16", "fc1_w16", "fc2_w16", "head_gate", "neuron_gate")] + \
-               [("num_heads", C.c_int), ("attn_width", C.c_int), ("hidden", C.c_int), ("dtype16", C.c_int)]
+               [("num_heads", C.c_int), ("attn_width", C.c_int), ("hidden", C.c_int), ("dtype16", C.c_int), ("fc2_w16t", C.c_void_p)]
 
 
 class BlockWgrads(C.Structure):

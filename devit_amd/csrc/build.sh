@@ -9,7 +9,7 @@ mkdir -p "$HERE/build"
 pids=()
 for f in api gemm layernorm attention elementwise losses sgemm comm encoder shrink; do
   if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || \
-     [ "$HERE/devit_common.h" -nt "$HERE/build/$f.o" ] || { [ "$f" = gemm ] && [ "$HERE/gemm4_kloop.inc" -nt "$HERE/build/$f.o" ]; } || [ "$HERE/../../include/devit_hip.h" -nt "$HERE/build/$f.o" ]; then
+     [ "$HERE/devit_common.h" -nt "$HERE/build/$f.o" ] || { [ "$f" = gemm ] && { [ "$HERE/gemm4_kloop.inc" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemmfr_kloop.inc" -nt "$HERE/build/$f.o" ]; }; } || [ "$HERE/../../include/devit_hip.h" -nt "$HERE/build/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
     pids+=($!)
   fi

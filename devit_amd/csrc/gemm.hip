@@ -1137,6 +1137,227 @@ void gemm4_kernel(const GemmArgs g) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Full-row 256x384x64 kernel (round 5): the student's N = 384 launches -- activation operand row-major, weight operand K-MAJOR (the
+// dgrads of qkv / proj / fc1 as they stand; proj / fc2 forward through a k-major copy of their weights), bf16 store or fp32 residual
+// epilogue.  Four waves, one per SIMD, each a 128 x 192 sub-tile = 96 accumulator tiles: 64 in a[0:255], 32 in v[128:255] (pinned asm
+// outputs); ONE fragment buffer; two A slots (32 KB) + two B slots (48 KB), the B stages shifted by half a stage so that a slot is
+// released -- and 8 or 12 requests per wave leave -- in EVERY phase; the K loop is a generated inline-asm statement
+// (gemmfr_kloop.inc, tools/gen_gemmfr.py: register plan, ring protocol, operand list).  Same LDS images / swizzles / MFMA operand roles /
+// accumulation order per output element as the 128x128 kernels these launches ran on: bit-identical results.  Why: two 128x128
+// workgroups per CU ask the CU's fill path for 64 B per cycle of matrix pipe and get ~24; this tile needs
+// 26.7 and reads the activation panel once instead of three times.
+#include "gemmfr_kloop.inc"
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+// per-lane source byte offset of slab i (1 KiB, of this wave's twelve = 16 k rows) of a 384-wide k-major B stage, relative to the wave's
+// first k row.  Image [64 k][384 cols]: a k-row is 48 chunks of 16 bytes, slabs cross k-rows (lane_offset<true> wants 64 % (W / 8) == 0).
+__device__ __forceinline__ unsigned fr_dma_off_b(int ld, int wave, int lane, int i) {
+  const int piece = (wave * 12 + i) * 64 + lane, krow = piece / 48, c = piece % 48;
+  return (unsigned)((krow - 16 * wave) * ld + ((c ^ swz_krow(krow)) * 8)) * 2u;
+}
+
+// first k row of wave `wave`'s share (16 k rows) of B stage u: the stages are shifted by half a stage and cyclic in K
+__device__ __forceinline__ int fr_b_row(int u, int wave, int K) {
+  const int r = 64 * u - 32 + 16 * wave;
+  return r < 0 ? r + K : (r >= K ? r - K : r);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gemmfr_kernel(const GemmArgs g) {
+  static_assert(KIND == DEVIT_EPI_RESIDUAL_F32 || KIND == DEVIT_EPI_STORE_BF16, "the student's N = 384 launches");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 384, NWAVES = 4;
+  constexpr bool PAIRED = KIND == DEVIT_EPI_STORE_BF16;   // column order of the n-tiles, tile_row<PAIRED>()
+  constexpr int A_SLOT = BM * BK * 2, B_SLOT = BN * BK * 2, B_RING = 2 * A_SLOT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  int first, last;
+  {
+    const int q = g.total_tiles >> 3, r = g.total_tiles & 7;
+    const int start = xcd * q + min(xcd, r);
+    first = start + idx;
+    last = start + q + (xcd < r ? 1 : 0);
+  }
+  if (first >= last) return;
+#ifdef DEVIT_GEMMFR_STAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+  unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};   // tiles, K loop, epilogue, d1 (barrier to barrier), d2 (barrier waits), prologue
+#endif
+
+  const unsigned lda64 = (unsigned)g.lda * 64u, ldbs = (unsigned)g.ldb * 128u, kb = (unsigned)g.K * (unsigned)g.ldb * 2u;
+  const unsigned lds_base = (unsigned)(size_t)LDS_PTR(smem);
+  const unsigned wldsa = lds_base + (unsigned)wave * 8192u, wldsb = lds_base + (unsigned)wave * 12288u;   // (+ the slot's offset)
+
+  // prologue: A stages 0, 1 of the first tile; B stages 0, 1 of the cyclic stream (one n-tile: every tile multiplies by the same B)
+  TileRef ct = decode_tile<BM, BN, false, true>(g, first);
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    stage_tile<false, BM, NWAVES, true>(ct.a, g.lda, (ct.kt0 + st) * BK, 0, 0, smem + st * A_SLOT, wave, lane);
+    const char* ub = (const char*)(ct.b + (size_t)fr_b_row(st, wave, g.K) * g.ldb);
+    const unsigned lds0 = lds_base + (unsigned)(B_RING + st * B_SLOT) + (unsigned)wave * 12288u;
+#pragma unroll
+    for (int i = 0; i < 12; i += 2)
+      dma2_uniform<false>(ub, fr_dma_off_b(g.ldb, wave, lane, i), fr_dma_off_b(g.ldb, wave, lane, i + 1), lds0 + i * 1024u);
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  unsigned acur = 0;                // LDS byte offset of the A slot that holds stage 0 of the tile about to start
+  const unsigned wv = (unsigned)wave;
+  const unsigned bv2 = (unsigned)fr_b_row(2, wave, g.K) * (unsigned)g.ldb * 2u;
+  const unsigned bplo = (unsigned)(uintptr_t)ct.b, bphi = (unsigned)((uintptr_t)ct.b >> 32);
+#ifdef DEVIT_GEMMFR_STAMP
+  st_sum[5] = __builtin_amdgcn_s_memtime() - t_entry;
+#endif
+
+  for (int tile = first; tile < last; tile += stride) {
+    const bool has_next = tile + stride < last;
+    const TileRef nt = has_next ? decode_tile<BM, BN, false, true>(g, tile + stride) : ct;
+    const __bf16* a_ptr = ct.a + (size_t)ct.kt0 * BK;
+    const __bf16* a_next = nt.a + (size_t)nt.kt0 * BK;
+    const unsigned nk = (unsigned)ct.nk, hasnext = (unsigned)__builtin_amdgcn_readfirstlane(has_next ? 1 : 0);
+    const devit_epilogue& ep = g.ep;
+    // per-lane constants of the K loop, recomputed per tile from an opaque copy of the lane index (see gemm4_kernel)
+    unsigned dsA[4], dsB[8], dmaA[4], dmaB[12];
+    {
+      int lane_k;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_k));
+      const int c = lane_k & 15, gq = lane_k >> 4;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          const int rowA = wm * 128 + 16 * par + c;
+          dsA[kk * 2 + par] = (unsigned)(rowA * 128 + (((kk * 4 + gq) ^ swz_row(rowA)) * 16));
+        }
+      // read_frag<true, 384, PAIRED>: see b_reads() in tools/gen_gemmfr.py
+      const int q4 = (lane_k >> 2) & 3, p = lane_k & 3;
+#pragma unroll
+      for (int x3 = 0; x3 < 4; ++x3) {
+        const unsigned row = (unsigned)((gq * 8 + q4) * (BN * 2) + 64 * (x3 ^ q4));
+        if constexpr (PAIRED) {
+          dsB[x3] = row + (unsigned)(16 * (p ^ ((gq & 1) << 1)));
+          dsB[4 + x3] = 0;
+        } else {
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) dsB[2 * x3 + jp] = row + (unsigned)(32 * (jp ^ (gq & 1)) + 16 * (p >> 1) + 8 * (p & 1));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dmaA[i] = lane_offset<false, BM, NWAVES>(g.lda, wave, lane_k, i, BM);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) dmaB[i] = fr_dma_off_b(g.ldb, wave, lane_k, i);
+    }
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
+    f32x32 c0, c1, c2, c3;
+#ifdef DEVIT_GEMMFR_STAMP
+    unsigned d1, d2;
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#define DEVIT_FR_STAMP_OUT , [d1] "=&s"(d1), [d2] "=&s"(d2)
+#define DEVIT_FR_ASM(O) DEVIT_GEMMFR_KLOOP_##O##_STAMPED_ASM
+#define DEVIT_FR_CLOB(O) DEVIT_GEMMFR_KLOOP_##O##_STAMPED_CLOBBERS
+#else
+#define DEVIT_FR_STAMP_OUT
+#define DEVIT_FR_ASM(O) DEVIT_GEMMFR_KLOOP_##O##_ASM
+#define DEVIT_FR_CLOB(O) DEVIT_GEMMFR_KLOOP_##O##_CLOBBERS
+#endif
+#define DEVIT_FR_STATEMENT(O)                                                                                                   \
+    asm volatile(DEVIT_FR_ASM(O)                                                                                                \
+                 : [c0] "=&{v[128:159]}"(c0), [c1] "=&{v[160:191]}"(c1), [c2] "=&{v[192:223]}"(c2), [c3] "=&{v[224:255]}"(c3),  \
+                   [acur] "+s"(acur), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4),           \
+                   [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9) DEVIT_FR_STAMP_OUT            \
+                 : [aptr] "s"(a_ptr), [anext] "s"(a_next), [bplo] "s"(bplo), [bphi] "s"(bphi), [bv2] "s"(bv2), [kb] "s"(kb),    \
+                   [nk] "s"(nk), [hasnext] "s"(hasnext), [lda64] "s"(lda64), [ldbs] "s"(ldbs), [wldsa] "s"(wldsa),              \
+                   [wldsb] "s"(wldsb), [wv] "s"(wv),                                                                            \
+                   [dsa0] "v"(dsA[0]), [dsa1] "v"(dsA[1]), [dsa2] "v"(dsA[2]), [dsa3] "v"(dsA[3]),                              \
+                   [dsb0] "v"(dsB[0]), [dsb1] "v"(dsB[1]), [dsb2] "v"(dsB[2]), [dsb3] "v"(dsB[3]),                              \
+                   [dsb4] "v"(dsB[4]), [dsb5] "v"(dsB[5]), [dsb6] "v"(dsB[6]), [dsb7] "v"(dsB[7]),                              \
+                   [dmaa0] "v"(dmaA[0]), [dmaa1] "v"(dmaA[1]), [dmaa2] "v"(dmaA[2]), [dmaa3] "v"(dmaA[3]),                      \
+                   [dmab0] "v"(dmaB[0]), [dmab1] "v"(dmaB[1]), [dmab2] "v"(dmaB[2]), [dmab3] "v"(dmaB[3]),                      \
+                   [dmab4] "v"(dmaB[4]), [dmab5] "v"(dmaB[5]), [dmab6] "v"(dmaB[6]), [dmab7] "v"(dmaB[7]),                      \
+                   [dmab8] "v"(dmaB[8]), [dmab9] "v"(dmaB[9]), [dmab10] "v"(dmaB[10]), [dmab11] "v"(dmaB[11])                   \
+                 : DEVIT_FR_CLOB(O))
+    if constexpr (PAIRED) DEVIT_FR_STATEMENT(PAIRED);
+    else DEVIT_FR_STATEMENT(NATURAL);
+#undef DEVIT_FR_STATEMENT
+#undef DEVIT_FR_STAMP_OUT
+#undef DEVIT_FR_ASM
+#undef DEVIT_FR_CLOB
+#ifdef DEVIT_GEMMFR_STAMP
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+    st_sum[0] += 1; st_sum[1] += ts1 - ts0; st_sum[3] += d1; st_sum[4] += d2;
+#endif
+    // epilogue: the eight-wave kernels' register epilogue on chunks of two m-tiles x four n-tiles; the column group that lives in
+    // VGPRs (n-tiles 8..11) first -- it frees the registers the other chunks' values are read out into
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const size_t ob = (size_t)ct.bz * ep.out_batch_stride;
+    const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
+    const bool full = ct.m0 + BM <= m_lim;
+    f32x4 cs[4];   // (no column scale in these kinds)
+    auto run = [&](f32x4 (&acc)[2][4], const int (&noff)[4], const f32x4 (&bias)[4], int i0) {
+      const int mw = ct.m0 + wm * 128 + i0 * 16;
+      if (full) epilogue_direct<KIND, 2, true, false>(ep, acc, noff, bias, cs, lane_e, mw, m_lim, ob);
+      else epilogue_direct<KIND, 2, false, false>(ep, acc, noff, bias, cs, lane_e, mw, m_lim, ob);
+    };
+    {
+      int noff[4];
+      f32x4 bias[4];
+      load_cols<KIND>(ep, lane_e, ct.n0 + wn * 192 + 128, noff, bias, cs);
+      auto from_v = [&](const f32x32& c, int i0) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[u][j] = (f32x4){c[16 * u + 4 * j], c[16 * u + 4 * j + 1], c[16 * u + 4 * j + 2], c[16 * u + 4 * j + 3]};
+        run(acc, noff, bias, i0);
+      };
+      from_v(c0, 0);
+      from_v(c1, 2);
+      from_v(c2, 4);
+      from_v(c3, 6);
+    }
+    auto group = [&](auto hc) {
+      constexpr int H = decltype(hc)::value;
+      int noff[4];
+      f32x4 bias[4];
+      load_cols<KIND>(ep, lane_e, ct.n0 + wn * 192 + H * 64, noff, bias, cs);
+      auto chunk = [&](auto ic) {
+        constexpr int I0 = decltype(ic)::value;
+        f32x4 acc[2][4];
+        gemmfr_read_acc<H, I0>(acc);
+        run(acc, noff, bias, I0);
+      };
+      chunk(std::integral_constant<int, 0>());
+      chunk(std::integral_constant<int, 2>());
+      chunk(std::integral_constant<int, 4>());
+      chunk(std::integral_constant<int, 6>());
+    };
+    group(std::integral_constant<int, 0>());
+    group(std::integral_constant<int, 1>());
+#ifdef DEVIT_GEMMFR_STAMP
+    st_sum[2] += __builtin_amdgcn_s_memtime() - ts1;
+#endif
+    ct = nt;
+  }
+  wait_vmcnt<0>();   // (requests of a next tile that does not exist are never made; this only drains the epilogue's stores)
+#ifdef DEVIT_GEMMFR_STAMP
+  if (g.ep.pos && lane == 0) {
+    unsigned long long* dbg = (unsigned long long*)g.ep.pos + ((size_t)blockIdx.x * NWAVES + wave) * 8;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dbg[q] = st_sum[q];
+    dbg[6] = t_entry; dbg[7] = __builtin_amdgcn_s_memtime();
+  }
+#endif
+}
+
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // CUs the persistent grids leave free (devit_set_reserved_cus): -1 = not set yet, take DEVIT_RESERVE_CUS from the environment
@@ -1152,6 +1373,18 @@ int reserved_cus() {
 }
 
 }  // namespace
+
+// The full-row 256x384 kernel (gemmfr_kernel): N == 384 exactly (one n-tile: its B stream is cyclic over the tiles), whole 256-row tiles and
+// enough of them to give most CUs one (the token-row GEMMs of the lean last block stay on 128x128 tiles), K >= 3 stages.  In-step times,
+// profiles/r05_*: the dgrads of qkv / proj / fc1 and fc2's forward; NOT proj's forward (6 K-steps in front of a 57 k-cycle residual epilogue on
+// 198 of 256 CUs: slower than two 128x128 workgroups per CU), which therefore never passes a k-major weight.  DEVIT_GEMMFR=0 / 1 forces it
+// off / on wherever it is built (read per call: tests switch it).
+bool devit_gemm_full_row_selected(int M, int N, int K, int kind) {
+  if (!(M > 0 && M % 256 == 0 && N == 384 && K % BK == 0 && K / BK >= 3 && (kind == DEVIT_EPI_RESIDUAL_F32 || kind == DEVIT_EPI_STORE_BF16)))
+    return false;
+  const char* e = getenv("DEVIT_GEMMFR");
+  return e ? atoi(e) != 0 : M / 256 >= 64;
+}
 
 extern "C" int devit_set_reserved_cus(int n) {
   DEVIT_CHECK(n >= 0 && n <= 128 && n % 8 == 0, DEVIT_ERR_ARG,
@@ -1236,7 +1469,14 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   if (cfg == 3 && (long long)(M / 256) * ((N + 255) / 256) * batch < 64) cfg = 1;
   static const int exact = getenv("DEVIT_GEMM_FORCE") ? atoi(getenv("DEVIT_GEMM_FORCE")) : 0;   // tools/gpu_tiles.sh
   if (exact == 1 || (exact == 3 && M % 256 == 0 && (N % 256 == 0 || ragged_ok) && variant != 3)) cfg = exact;
-  const int bm = cfg == 1 ? 128 : 256, bn = bm;
+  // the full-row 256x384 kernel: the student's N = 384 launches (round 5; per-shape times inside the step: profiles/r05_*).  DEVIT_GEMMFR=0 / 1
+  // forces it off / on for everything it is built for (read per call: tests switch it).
+  const bool use_fr = !f16 && split_k == 1 && batch == 1 && variant == 1 && devit_gemm_full_row_selected(M, N, K, ep->kind);
+  DEVIT_CHECK(use_fr || !(variant == 1 && ep->kind == DEVIT_EPI_RESIDUAL_F32), DEVIT_ERR_ARG,
+              "devit_gemm_bf16: the fp32 residual epilogue with a k-major weight runs on the full-row kernel only (N == 384, "
+              "M %% 256 == 0, >= 64 row tiles, K >= 192, DEVIT_GEMMFR != 0): M=%d N=%d K=%d", M, N, K);
+  if (use_fr) cfg = 4;
+  const int bm = cfg == 1 ? 128 : 256, bn = cfg == 4 ? 384 : bm;
   g.tiles_m = M / bm;
   g.tiles_n = (N + bn - 1) / bn;
   {
@@ -1273,7 +1513,7 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
     cus = n;
   }
   static const int occ_env = getenv("DEVIT_GEMM_OCC") ? atoi(getenv("DEVIT_GEMM_OCC")) : 0;
-  const int occ = occ_env > 0 ? occ_env : (cfg == 1 ? 2 : 1);
+  const int occ = cfg == 4 ? 1 : occ_env > 0 ? occ_env : (cfg == 1 ? 2 : 1);
   // A persistent grid holds every CU it starts on (the 256x256 workgroup owns the CU's whole LDS and register file) until
   // its last tile: a collective's kernels launched meanwhile (RCCL on the exchange stream) wait for a GEMM to END, and once
   // they hold CUs the next 256-workgroup grid runs a second, nearly empty round.  With `reserved` CUs left free the grid
@@ -1356,7 +1596,22 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
     }                                                                                                          \
     hipLaunchKernelGGL((gemm4_kernel<KIND_, false>), dim3((unsigned)nwg), dim3(256), lds, s, g);               \
   } while (0)
-  if (use4) {
+#define DEVIT_LAUNCH_GEMMFR(KIND_)                                                                              \
+  do {                                                                                                         \
+    constexpr int lds = (256 + 384) * 128 * 2;                                                                 \
+    static bool attr = false;                                                                                  \
+    if (!attr) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute((const void*)gemmfr_kernel<KIND_>,                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
+      DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
+      attr = true;                                                                                             \
+    }                                                                                                          \
+    hipLaunchKernelGGL((gemmfr_kernel<KIND_>), dim3((unsigned)nwg), dim3(256), lds, s, g);                     \
+  } while (0)
+  if (cfg == 4) {
+    if (ep->kind == DEVIT_EPI_STORE_BF16) DEVIT_LAUNCH_GEMMFR(DEVIT_EPI_STORE_BF16);
+    else DEVIT_LAUNCH_GEMMFR(DEVIT_EPI_RESIDUAL_F32);
+  } else if (use4) {
     switch (ep->kind) {
       case DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_GEMM4(DEVIT_EPI_STORE_BF16); break;
       case DEVIT_EPI_STORE_F32: DEVIT_LAUNCH_GEMM4(DEVIT_EPI_STORE_F32); break;
@@ -1368,6 +1623,7 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   } else if (cfg == 3) DEVIT_LAUNCH_GEMM(256, 256, 2, 4, 2);
   else DEVIT_LAUNCH_GEMM(128, 128, 2, 2, 2);
 #undef DEVIT_LAUNCH_GEMM4
+#undef DEVIT_LAUNCH_GEMMFR
 #undef DEVIT_LAUNCH_ONE
 #undef DEVIT_LAUNCH_ONE_T
 #undef DEVIT_LAUNCH_FWD16

@@ -11,6 +11,26 @@ namespace {
 // master's row / column, or -1 for a padding unit (compacted widths are padded to the GEMM granules with all-zero units).
 __global__ __launch_bounds__(256) void index_copy_kernel(const devit_index_job* jobs) {
   const devit_index_job j = jobs[blockIdx.y];
+  if (j.mode == 4) {   // 16-bit transpose dst[c][r] = src[r][c]: the k-major copy of a Linear weight (full-row GEMM, gemm.hip); 64 x 64 tiles through LDS
+    __shared__ unsigned short tile[64][66];
+    const int tr = (j.rows + 63) / 64, tc = (j.cols + 63) / 64;
+    const unsigned short* src = (const unsigned short*)j.src;
+    unsigned short* dst = (unsigned short*)j.dst;
+    for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+      const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+      for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (r0 + r < j.rows && c0 + c < j.cols) tile[r][c] = src[(long long)(r0 + r) * j.src_ld + c0 + c];
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int c = e >> 6, r = e & 63;
+        if (r0 + r < j.rows && c0 + c < j.cols) dst[(long long)(c0 + c) * j.dst_ld + r0 + r] = tile[r][c];
+      }
+      __syncthreads();
+    }
+    return;
+  }
   const long long total = (long long)j.rows * j.cols;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int r = (int)(e / j.cols), c = (int)(e - (long long)r * j.cols);

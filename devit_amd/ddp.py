@@ -71,6 +71,24 @@ class FlatParams:
             w = mod.weight
             o = self.offsets[self.index[id(w)]]
             mod._w16 = (w._version, self.flat16[o:o + w.numel()].view(w.shape[0], -1), w.data_ptr())
+        self.refresh_kmajor()
+
+    def refresh_kmajor(self):
+        """Re-derive the k-major copies (de_vit._w16t: fc2 of a 384-wide model, read by the full-row GEMM) of the weights whose bf16 copies live
+        in flat16, after flat16 was rewritten in place (refresh_bf16, optim.FlatAdamW.step): one launch over a cached job table."""
+        pairs = []
+        for mod in self._w16_mods:
+            c, w16 = mod.__dict__.get("_w16t"), mod.__dict__.get("_w16")
+            if c is not None and w16 is not None and c[0] == w16[1].data_ptr():
+                pairs.append((w16[1], c[2]))
+        if not pairs:
+            self._kmajor = None
+            return
+        from . import ops
+        key = tuple((a.data_ptr(), b.data_ptr()) for a, b in pairs)
+        if getattr(self, "_kmajor", None) is None or self._kmajor.key != key:
+            self._kmajor = ops._Transposes(pairs)
+        self._kmajor.run()
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -357,5 +375,5 @@ def broadcast_module(module, src=0, group=None):
     # writing through .data does not bump version counters: drop every cache keyed on them (16-bit GEMM copies, block
     # parameter views), so a forward that ran before the broadcast cannot leave stale weights behind
     for m in module.modules():
-        for k in ("_w16", "_w16h", "_bp_cache"):
+        for k in ("_w16", "_w16h", "_w16t", "_bp_cache"):
             m.__dict__.pop(k, None)

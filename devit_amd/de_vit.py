@@ -39,6 +39,20 @@ def _w16(lin, f16=False):
     return c[1]
 
 
+def _w16t(lin, w16):
+    """K-major bf16 copy [in][out] of an nn.Linear's bf16 GEMM copy `w16` ([out][in]) for the full-row 256x384 GEMM (csrc/gemm.hip: N == 384
+    outputs), re-derived whenever `w16` was re-made; in-place rewrites of `w16` (fused optimizer, FlatParams.refresh_bf16) re-derive it through
+    ddp.FlatParams.refresh_kmajor()."""
+    c = lin.__dict__.get("_w16t")
+    if c is None or c[0] != w16.data_ptr() or c[1] != lin.weight._version or c[2].device != w16.device:
+        buf = c[2] if (c is not None and c[2].device == w16.device and c[2].numel() == w16.numel()) else \
+            torch.empty((w16.shape[1], w16.shape[0]), dtype=w16.dtype, device=w16.device)
+        ops.transpose16(w16, buf)
+        lin._w16t = (w16.data_ptr(), lin.weight._version, buf, w16)
+        return buf
+    return c[2]
+
+
 class _Gated:
     """`gate` is a plain CPU float tensor attribute in the reference (de_vit.py:33,63), re-uploaded on every
     forward (:42,:78).  Here the device copy is cached and all-ones gates are skipped."""
@@ -179,6 +193,7 @@ class Block(nn.Module):
             bp.qkv_w = bp.proj_w = bp.fc1_w = bp.fc2_w = None
             bp.qkv_b, bp.proj_b, bp.fc1_b, bp.fc2_b = c["qkv_b"], self.attn.proj.bias, c["fc1_b"], self.mlp.fc2.bias
             bp.qkv_w16, bp.proj_w16, bp.fc1_w16, bp.fc2_w16 = c["qkv_w16"], c["proj_w16"], c["fc1_w16"], c["fc2_w16"]
+            bp.fc2_w16t = None
             bp.num_heads, bp.neuron_gate = c["num_heads"], None
             bp.head_gate = None if c.get("heads_compacted", True) else self.attn.gate_on(device)
             bp.dp_prob, bp.module, bp.compacted = (self.drop_prob if self.training else 0.), self, True
@@ -195,6 +210,8 @@ class Block(nn.Module):
         bp.fc2_w, bp.fc2_b = self.mlp.fc2.weight, self.mlp.fc2.bias
         bp.qkv_w16, bp.proj_w16 = _w16(self.attn.qkv, f16), _w16(self.attn.proj, f16)     # (unused by the fp32 parity path)
         bp.fc1_w16, bp.fc2_w16 = _w16(self.mlp.fc1, f16), _w16(self.mlp.fc2, f16)
+        # fc2 of a 384-wide model runs on the full-row GEMM, which reads its weight k-major
+        bp.fc2_w16t = _w16t(self.mlp.fc2, bp.fc2_w16) if (not f16 and bp.fc2_w16.is_cuda and bp.fc2_w16.shape[0] == 384) else None
         bp.num_heads = self.attn.num_heads
         bp.head_gate, bp.neuron_gate = self.attn.gate_on(device), self.mlp.gate_on(device)
         bp.dp_prob = self.drop_prob if self.training else 0.

@@ -73,6 +73,37 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def full_row_selected(M, N, K):
+    """The rule of csrc/gemm.hip's devit_gemm_full_row_selected(): would (row-major A) x (K-MAJOR B) with N outputs run on the full-row 256x384
+    kernel?  (A k-major weight with the fp32 residual epilogue exists on that kernel only.)"""
+    if not (M > 0 and M % 256 == 0 and N == 384 and K % 64 == 0 and K >= 192):
+        return False
+    e = os.environ.get("DEVIT_GEMMFR")
+    return (int(e) != 0) if e else M // 256 >= 64
+
+
+# Anything that rewrites 16-bit weight copies IN PLACE (behind the parameters' version counters: the fused optimizer kernel, FlatParams.refresh_bf16)
+# re-transposes the k-major copies that were derived from them (transpose16_jobs below); copies re-made by de_vit._w16 are re-derived there.
+def transpose16(src, dst):
+    """dst[c][r] = src[r][c] for 16-bit matrices (devit_index_copy mode 4): the k-major copy of a Linear weight."""
+    _Transposes([(src, dst)]).run()
+
+
+class _Transposes:
+    """A device-resident devit_index_job table of 16-bit transposes, one launch."""
+
+    def __init__(self, pairs):
+        jobs = [L.IndexJob(s_.data_ptr(), d.data_ptr(), None, s_.shape[0], s_.shape[1], s_.stride(0), d.stride(0), 4, 2) for s_, d in pairs]
+        arr = (L.IndexJob * len(jobs))(*jobs)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(pairs[0][0].device)
+        self.keep, self.n = pairs, len(jobs)
+        self.key = tuple((s_.data_ptr(), d.data_ptr()) for s_, d in pairs)
+        self.blocks = max(1, min(64, max((s_.shape[0] + 63) // 64 * ((s_.shape[1] + 63) // 64) for s_, _ in pairs)))
+
+    def run(self):
+        call("devit_index_copy", ptr(self.table), self.n, self.blocks, stream_ptr())
+
+
 # bench.py instrumentation: when PROFILE is a list, every GEMM launch is bracketed by events on the current stream
 # (the stream the kernel is launched on) and recorded as (template, M, N, K, batch, start_event, end_event).
 PROFILE = None
@@ -220,7 +251,7 @@ def sgemm_small(A, sam, sak, Bm, sbn, sbk, bias, Cm, ldc, M, N, K, alpha=1.0, ac
 class BlockParams:
     """fp32 parameters + cached bf16 GEMM copies of one Block (see de_vit.Block)."""
     __slots__ = ("n1w", "n1b", "qkv_w", "qkv_b", "proj_w", "proj_b", "n2w", "n2b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                 "qkv_w16", "proj_w16", "fc1_w16", "fc2_w16", "num_heads", "head_gate", "neuron_gate", "dp_prob",
+                 "qkv_w16", "proj_w16", "fc1_w16", "fc2_w16", "fc2_w16t", "num_heads", "head_gate", "neuron_gate", "dp_prob",
                  "module", "compacted", "masters", "finish")
 
     def all_params(self):
@@ -292,8 +323,13 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
     linear_fwd(ln2, bp.fc1_w16, bp.fc1_b, M, out=h, kind=L.EPI_GELU_BF16, colscale=bp.neuron_gate, aux=h_pre,
                exact_gelu=cfg.exact_gelu, dtype16=t16)
     x2o = torch.empty((B, N, D), dtype=F32, device=dev)
-    linear_fwd(h, bp.fc2_w16, bp.fc2_b, M, out=x2o.view(M, D), kind=L.EPI_RESIDUAL_F32, res=x1.view(M, D), rowscale=dp2,
-               rows_per_scale=N, dtype16=t16)
+    w2t = getattr(bp, "fc2_w16t", None)
+    if w2t is not None and not t16 and full_row_selected(pad_rows(M), D, Hd):   # k-major weight copy -> the full-row 256x384 GEMM (bit-identical)
+        gemm(h, h.stride(0), 0, w2t, w2t.stride(0), 1, pad_rows(M), D, Hd, kind=L.EPI_RESIDUAL_F32, out=x2o.view(M, D), ldc=D, bias=bp.fc2_b,
+             m_valid=M, res=x1.view(M, D), rowscale=dp2, rows_per_scale=N)
+    else:
+        linear_fwd(h, bp.fc2_w16, bp.fc2_b, M, out=x2o.view(M, D), kind=L.EPI_RESIDUAL_F32, res=x1.view(M, D), rowscale=dp2,
+                   rows_per_scale=N, dtype16=t16)
     if bp.module is not None and not cfg.lean_tokens:  # shrink contract (core/imp_rank.py:31,108): post-mask values
         bp.module.mlp.neuron_output = h[:M].view(B, N, Hd)
         bp.module.attn.head_output = attn_o[:M].view(B, N, H, Da // H)
@@ -553,6 +589,7 @@ def _weights_struct(bp):
     w.head_gate, w.neuron_gate = _p(bp.head_gate), _p(bp.neuron_gate)
     w.num_heads, w.attn_width, w.hidden = bp.num_heads, bp.qkv_w16.shape[0] // 3, bp.fc1_w16.shape[0]
     w.dtype16 = 1 if bp.qkv_w16.dtype == F16 else 0
+    w.fc2_w16t = _p(getattr(bp, "fc2_w16t", None))
     return w
 
 

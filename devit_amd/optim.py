@@ -66,6 +66,7 @@ class FlatAdamW:
              self.weight_decay, float(self.max_norm or 0.0), float(self.ema_decay or 0.0), float(f.grad_scale),
              stream_ptr())
         f.grad_scale = 1.0
+        f.refresh_kmajor()      # the kernel rewrote flat16 in place: the k-major weight copies derived from it follow (one launch)
 
     def ema_state_dict(self, model):
         """EMA weights keyed like model.state_dict() (timm get_state_dict(model_ema), distill_sub.py:429)."""

@@ -193,6 +193,9 @@ typedef struct {
   int num_heads, attn_width, hidden;                    /* attn_width = heads * 64 (== D unless compacted) */
   int dtype16;                                          /* 16-bit type of the weights and of every stored activation: 0 bf16,
                                                            1 f16 (forward without DEVIT_BLK_SAVE only) */
+  const void* fc2_w16t;                                 /* bf16 [hidden][D]: a k-major copy of fc2_w16 (devit_index_copy mode 4), or NULL.
+                                                           With it, D == 384 and >= 64 row tiles of 256 the forward's fc2 launch runs on the
+                                                           full-row 256x384 GEMM (same products, same accumulation order: bit-identical) */
 } devit_block_weights;
 
 typedef struct {
@@ -241,6 +244,8 @@ int devit_block_bwd(const devit_block_weights* w, const devit_block_acts* acts, 
  *   mode 1  gather columns  dst[r][j]      = src[r][idx[j]]
  *   mode 2  add rows        dst[idx[i]][c] += src[i][c]            (f32: compact weight gradients into the masters'; the
  *   mode 3  add columns     dst[r][idx[j]] += src[r][j]             source is an accumulator and is ZEROED by the call)
+ *   mode 4  transpose       dst[c][r]      = src[r][c]             (16-bit elements, idx unused: the k-major copy of a Linear
+ *                                                                    weight the full-row GEMM reads, devit_block_weights.fc2_w16t)
  * rows x cols is the extent of the COMPACT (dense) side; idx entries < 0 mark padding units and are skipped; kept
  * indices are distinct, so the adds need no atomics.  Jobs of one call must not write the same memory.
  * ---------------------------------------------------------------------------------------- */

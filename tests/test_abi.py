@@ -144,3 +144,29 @@ def test_gemm4_inc_is_current(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.startswith("GEMM4_")}      # (the experiment switches of the generator off)
     subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_gemm4.py"), str(out)], env=env)
     assert out.read_bytes() == open(os.path.join(ROOT, "devit_amd", "csrc", "gemm4_kloop.inc"), "rb").read()
+
+
+def test_gemmfr_inc_is_current(tmp_path):
+    """csrc/gemmfr_kloop.inc (the full-row 256x384 GEMM's K loop as inline asm) is GENERATED: tools/gen_gemmfr.py must reproduce the
+    committed file byte for byte."""
+    out = tmp_path / "gemmfr_kloop.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GEMMFR_")}     # (the experiment switches of the generator off)
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_gemmfr.py"), str(out)], env=env)
+    assert out.read_bytes() == open(os.path.join(ROOT, "devit_amd", "csrc", "gemmfr_kloop.inc"), "rb").read()
+
+
+def test_full_row_rule_is_mirrored(monkeypatch):
+    """ops.full_row_selected() restates csrc/gemm.hip's devit_gemm_full_row_selected() (the host decides with it whether to hand the GEMM a
+    k-major weight): the two must agree -- checked against the C++ source's constants."""
+    from devit_amd import ops
+    src = open(os.path.join(ROOT, "devit_amd", "csrc", "gemm.hip")).read()
+    body = src[src.index("bool devit_gemm_full_row_selected"):]
+    body = body[:body.index("\n}\n")]
+    assert "M % 256 == 0 && N == 384" in body and "K / BK >= 3" in body and "M / 256 >= 64" in body and 'getenv("DEVIT_GEMMFR")' in body
+    monkeypatch.delenv("DEVIT_GEMMFR", raising=False)
+    assert ops.full_row_selected(50688, 384, 1536) and ops.full_row_selected(16384, 384, 192)
+    assert not ops.full_row_selected(512, 384, 1536) and not ops.full_row_selected(50688, 768, 768) and not ops.full_row_selected(50688, 384, 128)
+    monkeypatch.setenv("DEVIT_GEMMFR", "0")
+    assert not ops.full_row_selected(50688, 384, 1536)
+    monkeypatch.setenv("DEVIT_GEMMFR", "1")
+    assert ops.full_row_selected(512, 384, 1536)

@@ -275,6 +275,49 @@ def test_distill_step_bf16_vs_f32_full_size(dev):
     print("bs-256 bf16 vs f32 gradient slices, rel-to-max:", {k: round(v, 5) for k, v in worst.items()})
 
 
+def test_full_row_gemm_inside_the_model_full_size(dev, monkeypatch):
+    """The student's fc2 forward and its qkv / proj / fc1 dgrads run on the full-row 256x384 GEMM (csrc/gemm.hip, default at >= 64 row tiles);
+    fc2 reads a K-MAJOR copy of its weight that must follow every rewrite of the bf16 copy.  At bs 256: the training forward + backward with the
+    kernel switched off (DEVIT_GEMMFR=0) and on -- logits and q / k / v of the middle block bit-identical, the gradient of pos_embed (behind every
+    dgrad) to fp32 round-off (the weight gradients go through fp32 atomics: not compared) -- and again after an optimizer step of the fused flat AdamW, which rewrites the bf16 copies
+    in place: a stale k-major copy would show as different logits."""
+    import devit_amd
+    from devit_amd import ddp, optim
+    torch.manual_seed(5)
+    s = devit_amd.create_model("dedeit", num_classes=25, drop_path_rate=0.0).to(dev).train()
+    flat = ddp.FlatParams(s)
+    flat.attach_bf16(s)
+    opt = optim.FlatAdamW(flat, lr=1e-3, weight_decay=0.05, max_norm=1.0, ema_decay=None)
+    g = torch.Generator(device=dev).manual_seed(32)
+    img = torch.randn((B, 3, 224, 224), generator=g, device=dev)
+
+    def run(flag):
+        monkeypatch.setenv("DEVIT_GEMMFR", flag)
+        opt.zero_grad()
+        out = s(img, output_qkv=True)
+        lg = out["output"][0]                     # (class-token logits, distillation-token logits) in training mode
+        q, k, v = out["qkv"][5]
+        (lg.float().square().mean() + q.float().mean() + v.float().square().mean()).backward()
+        torch.cuda.synchronize()
+        return lg.detach().clone(), q.detach().clone(), k.detach().clone(), v.detach().clone(), s.pos_embed.grad.detach().clone()
+
+    for phase in range(2):
+        ref = run("0")
+        got = run("1")
+        for a, b in zip(ref[:4], got[:4]):
+            assert torch.equal(a, b), phase
+        # the gradient that reaches the embedding went through every dgrad of every block (a sum over the batch: compared to fp32 round-off)
+        assert float((ref[4] - got[4]).abs().max()) <= 1e-5 * float(ref[4].abs().max()), phase
+        opt.step()          # rewrites masters + bf16 copies in place; the k-major copies must follow
+    monkeypatch.setenv("DEVIT_GEMMFR", "1")
+    s.eval()
+    with torch.no_grad():
+        a = s(img[:128])
+        monkeypatch.setenv("DEVIT_GEMMFR", "0")
+        b = s(img[:128])
+    assert torch.equal(a, b)
+
+
 def test_ensemble_config5_full_size(dev):
     """BASELINE config 5 at its size: four `dedeit` sub-models (250 classes each, shrink_ratio 0.3 head / neuron gates) +
     EnsMLP -> 1000 classes, bs 256, inference (ensemble.py; models/ensemble_models.py:32-40).  The 4 x 25-class, bs-4 form is

@@ -121,6 +121,60 @@ def test_gemm_four_wave_kernel_bit_identical(dev, monkeypatch, M, N, K, kind, mv
             assert torch.equal(aux, ref_aux)
 
 
+@pytest.mark.parametrize("M,K,kind,mv", [
+    (50688, 1152, 0, 0),      # qkv dgrad: bf16 store, 198 tiles (one per workgroup)
+    (12800, 1536, 0, 12700),  # fc1 dgrad, ragged M
+    (76800, 384, 0, 0),       # proj dgrad shape, 300 tiles on 256 workgroups: some walk two (A requests across the tile boundary, B cyclic)
+    (50688, 384, 2, 50500),   # student proj through a k-major weight: fp32 residual + DropPath scale, 6 K-steps, ragged M
+    (12800, 1536, 2, 0),      # student fc2
+    (16384, 192, 2, 0),       # 3 K-steps: first / last-but-one / last step, the loop body never runs
+    (76800, 256, 2, 0),       # two tiles per workgroup, 4 K-steps
+])
+def test_gemm_full_row_kernel_bit_identical(dev, monkeypatch, M, K, kind, mv):
+    """The full-row 256x384 kernel (gemmfr_kernel: row-major activation x K-MAJOR weight, N = 384; K loop = generated inline asm,
+    csrc/gemmfr_kloop.inc) accumulates every output element in the same order as the 128x128 kernels and runs the same epilogue code:
+    bit-identical to them (DEVIT_GEMMFR=0: the bf16 store on the same k-major weight, the fp32 residual on its row-major transpose --
+    same products, same order), twice in a row; rows >= m_valid stay untouched."""
+    from devit_amd import ops, _lib as L
+    N = 384
+    a, bias = rnd((M, K), dev, dtype=BF16), rnd((N,), dev, 0.1, 2)
+    wk = rnd((K, N), dev, 0.05, 1, BF16)                       # k-major: [K][N]
+    resid = kind == L.EPI_RESIDUAL_F32
+    res = rnd((M, N), dev, 1.0, 3) if resid else None
+    drop = (rnd((M // 198 + 1,), dev, seed=5) > -1.0).float() * 1.25 if resid else None
+    kw = dict(kind=kind, ldc=N, bias=bias if resid else None, res=res, rowscale=drop, rows_per_scale=198 if resid else 0, m_valid=mv)
+    def run(flag):
+        monkeypatch.setenv("DEVIT_GEMMFR", flag)
+        out = torch.full((M, N), 7.0, dtype=F32 if resid else BF16, device=dev)
+        if flag == "0" and resid:
+            ops.gemm(a, K, 0, wk.t().contiguous(), K, 0, M, N, K, out=out, **kw)
+        else:
+            ops.gemm(a, K, 0, wk, N, 1, M, N, K, out=out, **kw)
+        torch.cuda.synchronize()
+        return out
+    ref = run("0")
+    want = a.float() @ wk.float()
+    lim = mv or M
+    if resid:
+        want = res + drop.repeat_interleave(198)[:M, None] * (want + bias)
+        assert relerr(ref[:lim], want[:lim]) < 2e-5
+    else:
+        bf16_ulp_ok(ref[:lim], want[:lim])
+    for _ in range(2):
+        assert torch.equal(run("1"), ref)
+    assert bool((ref[lim:].float() == 7.0).all())
+
+
+@pytest.mark.parametrize("R,Cc", [(384, 1536), (100, 72), (64, 64)])
+def test_transpose16(dev, R, Cc):
+    """devit_index_copy mode 4: dst[c][r] = src[r][c] on 16-bit elements (the k-major copy of a Linear weight), ragged edges included."""
+    from devit_amd import ops
+    src = rnd((R, Cc), dev, dtype=BF16)
+    dst = torch.zeros((Cc, R), dtype=BF16, device=dev)
+    ops.transpose16(src, dst)
+    assert torch.equal(dst, src.t())
+
+
 def test_gemm_ragged_gelu_dgelu(dev):
     """N = 1152 (4.5 x 256: the compacted student's hidden width at shrink_ratio 0.3) through the 256x256 tile with a half-empty
     last n-tile, GELU (+ pre-activation, + gate) and dGELU epilogues."""
