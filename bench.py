@@ -60,6 +60,9 @@ def parse():
                     help="N = 1 only, never the headline value: send every gradient bucket through RCCL on the exchange stream "
                          "during backward although there is one rank (abi: the C ABI's devit_comm_* communicator; torch: a "
                          "world-size-1 torch.distributed nccl group); the reducer is told it has two ranks, so gradients are halved")
+    ap.add_argument("--cpu-cores", type=int, default=0,
+                    help="confine this process (every rank) to N host cores before anything touches the GPU: what the step costs the host when "
+                         "eight ranks share one node's cores (the line then carries `cpu_cores`)")
     ap.add_argument("--host-input", action="store_true",
                     help="PCIe-inclusive variant (DESIGN.md section 6, never the headline value): every step's batch starts "
                          "in pinned host memory and crosses to the GPU through the training loop's prefetcher")
@@ -266,6 +269,14 @@ def stub_main(args, rank, world, json_out):
 
 def main():
     args = parse()
+    if args.cpu_cores > 0 and hasattr(os, "sched_setaffinity"):
+        # before any GPU call and before the launcher forks the ranks (children inherit the mask): rank r of a launched job takes its own
+        # slice so that N ranks x C cores are disjoint, as a node with 8 ranks would have it
+        avail = sorted(os.sched_getaffinity(0))
+        r = int(os.environ.get("LOCAL_RANK", 0)) if "WORLD_SIZE" in os.environ else 0
+        mine = [avail[(r * args.cpu_cores + i) % len(avail)] for i in range(min(args.cpu_cores, len(avail)))]
+        if "WORLD_SIZE" in os.environ or args.gpus == 1:
+            os.sched_setaffinity(0, set(mine))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))          # nothing above has initialised a GPU; the ranks are fresh processes
     # stdout carries exactly one line, the JSON; whatever the libraries print while starting up (RCCL's version banner
@@ -526,6 +537,7 @@ def main():
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
             "host_ms_per_step_idle_queue": round(host_step_ms, 3),
+            "cpu_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,   # (what this rank may run on: --cpu-cores)
             "hbm_peak_allocated_gb": round(hbm_peak_gb, 2),
             "higher_is_better": True, "scaling": "weak",
             "algorithmic_gflop_per_img": GFLOP_PER_IMG_STEP, "executed_gflop_per_img": executed,

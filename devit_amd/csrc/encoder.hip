@@ -3,6 +3,8 @@
 // two paths agree bit for bit (tests/test_gpu_model.py::test_block_calls_match_granular_path; the weight gradients are
 // split-K atomics either way).  devit_block_bwd puts its four weight-gradient launches on a side stream of its own and joins
 // it before it returns (round 4, see there).  Host code only.
+#include <mutex>
+
 #include "devit_common.h"
 
 namespace {
@@ -67,27 +69,33 @@ int linear_wgrad(const Ctx& c, const void* dy, const void* x, float* w_grad, flo
     if (rc__ != DEVIT_OK) return rc__; \
   } while (0)
 
-// devit_block_bwd's side stream for the weight-gradient launches: one per device, created at first use, never destroyed
+// devit_block_bwd's side stream for the weight-gradient launches: one per device, created at the first call that wants it (once, under
+// std::call_once: two host threads making their first call together see one stream), owned by the library for the life of the process
+// (declared at devit_block_bwd in include/devit_hip.h).  A device index past the table runs without one (= on the caller's stream).
 struct WgradSide {
   hipStream_t stream;
   hipEvent_t ev[5];
+  bool ok = false;
 };
+constexpr int MAX_DEVICES = 16;
 int wgrad_side(WgradSide** out) {
   const char* env = getenv("DEVIT_WGRAD_STREAM");      // (read per call: tests switch it)
   const bool on = !(env && atoi(env) == 0);
-  static WgradSide per_dev[16];
-  static bool made[16] = {};
+  static WgradSide per_dev[MAX_DEVICES];
+  static std::once_flag once[MAX_DEVICES];
   *out = nullptr;
   if (!on) return DEVIT_OK;
   int dev = 0;
-  DEVIT_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, DEVIT_ERR_DEVICE, "devit_block_bwd: hipGetDevice");
-  if (!made[dev]) {
-    DEVIT_CHECK(hipStreamCreateWithFlags(&per_dev[dev].stream, hipStreamNonBlocking) == hipSuccess, DEVIT_ERR_DEVICE,
-                "devit_block_bwd: cannot create the weight-gradient stream");
-    for (auto& e : per_dev[dev].ev)
-      DEVIT_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, DEVIT_ERR_DEVICE, "devit_block_bwd: cannot create an event");
-    made[dev] = true;
-  }
+  DEVIT_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0, DEVIT_ERR_DEVICE, "devit_block_bwd: hipGetDevice");
+  if (dev >= MAX_DEVICES) return DEVIT_OK;
+  std::call_once(once[dev], [dev]() {
+    WgradSide& s = per_dev[dev];
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return;
+    for (auto& e : s.ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
+    s.ok = true;
+  });
+  DEVIT_CHECK(per_dev[dev].ok, DEVIT_ERR_DEVICE, "devit_block_bwd: cannot create the weight-gradient stream / its events");
   *out = &per_dev[dev];
   return DEVIT_OK;
 }
@@ -238,13 +246,18 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
   WgradSide* sd = nullptr;
   TRY(wgrad_side(&sd));
   Ctx cs = c;
+  bool forked = false;
   auto fork = [&](int i) -> int {
     if (!sd) return DEVIT_OK;
     DEVIT_CHECK(hipEventRecord(sd->ev[i], (hipStream_t)stream) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->ev[i], 0) == hipSuccess,
                 DEVIT_ERR_LAUNCH, "devit_block_bwd: cannot fork the weight-gradient stream");
     cs.stream = sd->stream;
+    forked = true;
     return DEVIT_OK;
   };
+  // (the body is a lambda so that an error return after a fork still joins the side stream below: the caller's stream never runs ahead
+  // of launches it does not know about)
+  const int rc = [&]() -> int {
   void* const* b = a.buf;
   void* dh_pre = io->ws[DEVIT_BWD_DH_PRE];
   void* dln2 = io->ws[DEVIT_BWD_DLN2];
@@ -290,8 +303,11 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
   TRY(devit_layernorm_bwd(dln1, 0, a.x, c.M, D, 0, 0, (const float*)b[DEVIT_ACT_MEAN1], (const float*)b[DEVIT_ACT_RSTD1],
                           w.n1w, dx1, io->dx_in, io->g_prev, io->prev_dp2, N, g.n1w, g.n1b,
                           io->g_prev ? io->prev_fc2_b_grad : nullptr, 1, io->ws[DEVIT_BWD_LNWS], io->lnws_bytes, stream));
-  if (sd)
-    DEVIT_CHECK(hipEventRecord(sd->ev[4], sd->stream) == hipSuccess && hipStreamWaitEvent((hipStream_t)stream, sd->ev[4], 0) == hipSuccess,
-                DEVIT_ERR_LAUNCH, "devit_block_bwd: cannot join the weight-gradient stream");
   return DEVIT_OK;
+  }();
+  if (sd && forked) {
+    const bool joined = hipEventRecord(sd->ev[4], sd->stream) == hipSuccess && hipStreamWaitEvent((hipStream_t)stream, sd->ev[4], 0) == hipSuccess;
+    if (rc == DEVIT_OK) DEVIT_CHECK(joined, DEVIT_ERR_LAUNCH, "devit_block_bwd: cannot join the weight-gradient stream");
+  }
+  return rc;
 }

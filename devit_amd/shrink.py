@@ -167,8 +167,10 @@ def refresh_blocks(blocks):
     def versions(blk):
         # torch-side rewrites of the masters (load_state_dict / --resume, an EMA swap, ddp.broadcast_module) bump these; the
         # fused optimizer writes through raw pointers and does not -- that case is `blk.training` below
-        return tuple(p._version for p in (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.mlp.fc1.weight,
-                                          blk.mlp.fc1.bias, blk.mlp.fc2.weight))
+        # (`p.data = other` -- how EMA weights are usually swapped in, and what module._apply / .to() does -- may leave the counter alone:
+        # the storage address is part of the key; proj.bias / fc2.bias are read in place, never gathered)
+        return tuple((p._version, p.data_ptr()) for p in (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.mlp.fc1.weight,
+                                                          blk.mlp.fc1.bias, blk.mlp.fc2.weight))
     todo = []
     for blk in blocks:
         c = getattr(blk, "_compact", None)

@@ -234,6 +234,15 @@ int devit_block_acts_sizes(int B, int N, int D, int attn_width, int hidden, int 
 int devit_block_bwd_sizes(int B, int N, int D, int attn_width, int hidden, size_t* sizes /* [DEVIT_BWD_COUNT] */);
 int devit_encoder_fwd(int nblocks, const devit_block_weights* w, const devit_block_acts* acts, int B, int N, int D,
                       float eps, void* stream);
+/* devit_block_bwd is the ONE entry point that does not keep to "enqueue on the caller's stream only": its four weight-gradient GEMMs go to a
+ * stream the LIBRARY owns -- one non-blocking stream + five events per device, created at the first call on that device (thread-safe), never
+ * destroyed: process lifetime -- each behind an event of the kernel on `stream` that produces its operand, and `stream` waits for the last of them
+ * before the call returns (also when it returns an error after the first fork).  Callers therefore still see one stream: everything the call
+ * enqueued is ordered before whatever is enqueued on `stream` next, the transient buffers may be reused, the accumulators in `grads` are complete
+ * for the next kernel on `stream`.  What a binding must know: (1) the call is not capturable into a hipGraph of `stream` alone before
+ * the side stream exists (first call outside capture); (2) a stream-ordered allocator must treat the buffers of `acts` / `io` / `grads` as in use
+ * until work enqueued on `stream` AFTER the call has run (they are read by another stream meanwhile); (3) DEVIT_WGRAD_STREAM=0 in the environment
+ * (read per call) keeps every launch on `stream`; a device index >= 16 does the same.  Worth +0.9 % on the DEKD step (profiles/r04_h_*). */
 int devit_block_bwd(const devit_block_weights* w, const devit_block_acts* acts, const devit_block_wgrads* grads,
                     const devit_block_bwd_io* io, int B, int N, int D, float eps, void* stream);
 

@@ -97,24 +97,31 @@ def test_gemm_persistent_schedule(dev, M, N, K, kind, mv):
     (6400, 1536, 384, 1, 0),         # GELU + pre-activation, 6 K-steps per tile (the shortest loop the step has)
     (16384, 256, 192, 1, 0),         # 3 K-steps: first / middle / last step each run exactly once per tile (64 tiles: the fewest that take 256x256 tiles)
     (16384, 512, 768, 6, 0),         # fp32 store
+    (12544, 768, 768, 3, 0),         # patch embedding (64 images x 196 patches): token remap + bias + pos-embed into [B, 198, N]
 ])
 def test_gemm_four_wave_kernel_bit_identical(dev, monkeypatch, M, N, K, kind, mv):
-    """The opt-in four-wave kernel (DEVIT_GEMM4=1: gemm4_kernel, K loop = generated inline asm, csrc/gemm4_kloop.inc) accumulates every
-    output element in the same order as the eight-wave kernel and runs the same epilogue code: outputs bit-identical, twice in a row
-    (the second launch starts with a warm ring / different slot phase)."""
+    """The four-wave kernel (gemm4_kernel, K loop = generated inline asm, csrc/gemm4_kloop.inc; the default for plain bf16 stores and the fp32
+    residual epilogue at K >= 768, DEVIT_GEMM4=0 / 1 forces it off / on wherever it is built) accumulates every output element in the same order
+    as the eight-wave kernel and runs the same epilogue code: outputs bit-identical, twice in a row (the second launch runs on warm caches)."""
     from devit_amd import ops, _lib as L
     a, w, bias = rnd((M, K), dev, dtype=BF16), rnd((N, K), dev, 0.05, 1, BF16), rnd((N,), dev, 0.1, 2)
     res = rnd((M, N), dev, 1.0, 3) if kind == L.EPI_RESIDUAL_F32 else None
-    f32 = kind in (L.EPI_RESIDUAL_F32, L.EPI_STORE_F32)
+    f32 = kind in (L.EPI_RESIDUAL_F32, L.EPI_STORE_F32, L.EPI_PATCH_F32)
+    patch = kind == L.EPI_PATCH_F32
+    pos = rnd((198, N), dev, 0.02, 4) if patch else None
     outs = {}
     for flag in ("0", "1", "1"):
         monkeypatch.setenv("DEVIT_GEMM4", flag)
-        out = torch.full((M, N), 7.0, dtype=F32 if f32 else BF16, device=dev)
+        out = torch.full((M // 196 * 198, N) if patch else (M, N), 7.0, dtype=F32 if f32 else BF16, device=dev)
         aux = torch.zeros((M, N), dtype=BF16, device=dev) if kind == L.EPI_GELU_BF16 else None
-        ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, bias=bias, res=res, aux=aux, m_valid=mv)
+        ops.gemm(a, K, 0, w, K, 0, M, N, K, kind=kind, out=out, ldc=N, bias=bias, res=res, aux=aux, m_valid=mv, pos=pos,
+                 patch_tokens=196 if patch else 0, extra_tokens=2 if patch else 0)
         torch.cuda.synchronize()
         outs.setdefault(flag, []).append((out, aux))
     ref, ref_aux = outs["0"][0]
+    if patch:   # the reference itself against torch: rows 2.. of every image = patches @ w^T + bias + pos[2:], rows 0, 1 (the tokens) untouched
+        want = (a.float() @ w.float().t() + bias).view(-1, 196, N) + pos[2:]
+        assert relerr(ref.view(-1, 198, N)[:, 2:], want) < 2e-5 and bool((ref.view(-1, 198, N)[:, :2] == 7.0).all())
     for out, aux in outs["1"]:
         assert torch.equal(out, ref)
         if aux is not None:

@@ -422,6 +422,19 @@ def test_training_through_compacted_blocks(golden, models, dev):
         with torch.no_grad():
             for n, p in s.named_parameters():
                 p.add_(gc[n], alpha=1.0)
+        # eval mode, weights swapped in by `p.data = other` (how EMA weights are usually evaluated; it need not bump the version counter):
+        # the compact copies must follow the storage, not only the counter (advisor r04)
+        s.eval()
+        with torch.no_grad():
+            s(img)                                                   # settles the eval-mode gather
+            w = s.blocks[2].mlp.fc1.weight
+            old_data, seen = w.data, s.blocks[2]._compact["fc1_w16"].clone()
+            w.data = old_data * 1.5
+            s(img)
+            assert not torch.equal(s.blocks[2]._compact["fc1_w16"], seen), "compact fc1 weights did not follow a `.data =` swap"
+            w.data = old_data
+            s(img)
+            assert torch.equal(s.blocks[2]._compact["fc1_w16"], seen)
     finally:
         shrink.uncompact(s)
         for blk in s.blocks:

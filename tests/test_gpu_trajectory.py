@@ -5,7 +5,8 @@
     `clip_grad_norm_` + a three-line EMA (engine.py:123-132, distill_sub.py:340-343 of the reference).  One step at a time this
     was covered before; only the loop catches a stale bf16 weight copy, a wrong `grad_scale`, or an EMA that slips.
 (b) The bs-256 step (BASELINE's size) of the benchmarked bf16 kernels against the ORACLE itself (one CPU step, ~20-60 s): five
-    losses, logits, top-1.  (tests/test_gpu_fullsize.py compares the bs-256 backward HIP-vs-HIP.)
+    losses, logits, top-1 (how many images pass the margin filter and how many agree is recorded and printed).
+(c) The bs-256 BACKWARD against the oracle: all 155 gradients against the mean of four bs-64 oracle steps (a few minutes of CPU).
 """
 import numpy as np
 import pytest
@@ -182,8 +183,82 @@ def test_full_size_step_vs_oracle(dev):
     assert chk(rel(out["teacher_logits"], ref["teacher"]["output"]), 1.5e-2)
     # top-1: bit-exact wherever the reference's margin between its two largest logits exceeds twice the logit deviation bar (a tie
     # inside the rounding noise of either side has no defined winner); on the deterministic weights every image qualifies or nearly so
-    for got, want in ((lo, ref["student"]["output"][0]), (lo_d, ref["student"]["output"][1]), (out["teacher_logits"], ref["teacher"]["output"])):
+    for name, got, want in (("student", lo, ref["student"]["output"][0]), ("student_dist", lo_d, ref["student"]["output"][1]),
+                            ("teacher", out["teacher_logits"], ref["teacher"]["output"])):
         top2 = want.topk(2, dim=1).values
-        clear = (top2[:, 0] - top2[:, 1]) > 3e-2 * want.abs().max()
+        margin = (top2[:, 0] - top2[:, 1]) / want.abs().max()
+        clear = margin > 3e-2
+        agree = got.argmax(1).cpu() == want.argmax(1)
+        # recorded through chk (profiles/*_parity_margins.json): the share of the 256 images OUTSIDE the margin filter, and the share of all
+        # 256 whose top-1 differs from the reference's (the bars only make the numbers visible: the assertions are below)
+        chk(1.0 - float(clear.float().mean()), 0.5)
+        chk(1.0 - float(agree.float().mean()), 0.05)
+        print(f"{name}: {int(clear.sum())} of {B} images have a reference top-2 margin > 3e-2 of max|logit|; top-1 agrees on {int(agree.sum())} of {B}")
+        for i in (~agree).nonzero().flatten().tolist():
+            print(f"   image {i}: reference margin {float(margin[i]):.2e} of max|logit| (inside the 1.5e-2 logit deviation bar x 2)")
         assert int(clear.sum()) >= B // 2
-        assert torch.equal(got.argmax(1).cpu()[clear], want.argmax(1)[clear])
+        assert bool(agree[clear].all()), "top-1 differs on an image whose reference margin exceeds the filter"
+        # every disagreement must be explained by a margin inside twice the logit deviation bar
+        assert bool((margin[~agree] <= 3e-2).all())
+
+
+def test_full_size_gradients_vs_oracle(dev):
+    """The bs-256 BACKWARD of the benchmarked bf16 kernels against the ORACLE (verdict r04 #3): every kernel is batch-local and every loss
+    term a batch mean (soft-target CE, hard-distillation CE: means; the relation losses: batchmean, utils/losses.py:309,326), so the bs-256
+    oracle gradient is the mean of the gradients of four bs-64 oracle steps on the quarters of the batch -- which fit the host's memory and take
+    a few minutes of CPU.  All 155 gradient norms and the slices test_distill_step_bf16_vs_f32_full_size compares HIP-vs-HIP, here against
+    the fp32 CPU restatement of engine.py:68-127; same weights, images, soft targets and DropPath masks."""
+    import devit_amd
+    from devit_amd import engine
+    B, Q = 256, 4
+    st_s, st_t = O.make_state(GS, C, "S"), O.make_state(GT, C, "T")
+    g = torch.Generator().manual_seed(2025)
+    img = torch.randn((B, 3, 224, 224), generator=g)
+    soft = _soft_targets(B, 6)
+    masks = _dp_masks(1, B, 18)[0]
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    params = {k: v.clone().requires_grad_(True) for k, v in st_s.items()}
+    ref_loss = {k: 0.0 for k in ("loss", "cls_loss", "q_loss", "k_loss", "v_loss")}
+    for c in range(Q):
+        sl = slice(c * B // Q, (c + 1) * B // Q)
+        o = O.distill_step(params, GS, st_t, GT, img[sl], soft[sl], dp_scales=[(a[sl], b[sl]) for a, b in masks])
+        (o["loss"] / Q).backward()
+        for k in ref_loss:
+            ref_loss[k] += float(o[k].detach()) / Q
+        del o
+    gref = {n: p.grad for n, p in params.items()}
+    s = devit_amd.create_model("dedeit", num_classes=C, drop_path_rate=0.1, drop_block_rate=None)
+    t = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C)
+    s.load_state_dict(st_s)
+    t.load_state_dict(st_t)
+    s.to(dev).train()
+    t.to(dev).eval()
+    for p in t.parameters():
+        p.requires_grad_(False)
+    out = engine.distill_forward(s, t, img.to(dev), soft.to(dev), gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0,
+                                 dp_scales=[(a.to(dev), b.to(dev)) for a, b in masks])
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ref_loss:          # (the hard-distillation target is the teacher's argmax: a flipped top-1 would show here first)
+        e = abs(float(out[k]) - ref_loss[k]) / abs(ref_loss[k])
+        assert chk(e, 2e-3), f"{k}: {float(out[k])} vs {ref_loss[k]}"
+    ghip = {n: p.grad.detach().float().cpu() for n, p in s.named_parameters()}
+    assert set(ghip) == set(gref) and len(gref) == 155
+    names = list(gref)
+    nref = torch.stack([gref[n].norm() for n in names])
+    nhip = torch.stack([ghip[n].norm() for n in names])
+    # bars as in test_distill_step_bf16_vs_f32_full_size (the same bf16 kernels against an exact-fp32 answer): norms 1e-2, slices 3-7e-2
+    chk(float(((nhip - nref).abs() / (nref + 1e-3 * nref.max())).max()), 1e-2)
+    bad = (nhip - nref).abs() > 1e-2 * nref + 1e-3 * nref.max()
+    assert not bool(bad.any()), [(n, float(a), float(b)) for n, a, b, f in zip(names, nhip, nref, bad) if f][:8]
+    relmax = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    slices = ["head.weight", "head_dist.bias", "norm.weight", "blocks.11.mlp.fc2.weight", "blocks.11.mlp.fc2.bias",
+              "blocks.7.mlp.fc1.weight", "blocks.7.mlp.fc1.bias", "blocks.5.attn.qkv.weight", "blocks.5.attn.qkv.bias",
+              "blocks.5.attn.proj.weight", "blocks.2.norm1.weight", "blocks.0.norm2.bias", "blocks.0.attn.proj.bias",
+              "patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed", "cls_token", "dist_token"]
+    worst = {}
+    for n in slices:
+        worst[n] = relmax(ghip[n], gref[n])
+        bar = 7e-2 if n.startswith(("patch_embed", "pos_embed", "cls_token", "dist_token")) else (3e-2 if gref[n].ndim > 1 else 4e-2)
+        assert chk(worst[n], bar), f"{n}: gradient rel-to-max err {worst[n]:.3e}"
+    print("bs-256 bf16 gradients vs the oracle (4 x bs-64), rel-to-max:", {k: round(v, 5) for k, v in worst.items()})

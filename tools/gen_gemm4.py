@@ -58,6 +58,7 @@ TAIL0 = 48                # first gap of the bookkeeping tail
 
 FIXSRC = os.environ.get("GEMM4_FIXSRC") == "1"     # experiment: every request re-reads stage 2 of the tile (L1 / L2 hits): is the loop issue- or memory-bound?
 NODMA = os.environ.get("GEMM4_NODMA") == "1"       # experiment: no requests at all (s_nop in their place)
+A_NT = os.environ.get("GEMM4_A_NT") == "1"         # experiment: non-temporal requests for the activation operand (round 5: what the full-row kernel gains from)
 STAMP = False      # diagnostic variant: s_memtime deltas of the loop's segments summed in SGPRs, returned in [d0]..[d3]
 T0, T1, T2, TN, D1, D2, D3 = 92, 94, 96, 98, 100, 101, 91
 
@@ -110,7 +111,8 @@ def dma_list(which):
     op = "dmaa" if which == "A" else "dmab"
     for i in range(8):
         base = lo if i < 4 else hi
-        out.append((f"s_add_u32 m0, s{dst}, {i * 1024}", "s_nop 0" if NODMA else f"global_load_lds_dwordx4 %[{op}{i & 3}], s[{base}:{base + 1}]"))
+        out.append((f"s_add_u32 m0, s{dst}, {i * 1024}", "s_nop 0" if NODMA else f"global_load_lds_dwordx4 %[{op}{i & 3}], s[{base}:{base + 1}]" +
+                    (" nt" if A_NT and which == "A" else "")))
     return out
 
 
