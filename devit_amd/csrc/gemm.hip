@@ -1383,7 +1383,7 @@ bool devit_gemm_full_row_selected(int M, int N, int K, int kind) {
   if (!(M > 0 && M % 256 == 0 && N == 384 && K % BK == 0 && K / BK >= 3 && (kind == DEVIT_EPI_RESIDUAL_F32 || kind == DEVIT_EPI_STORE_BF16)))
     return false;
   const char* e = getenv("DEVIT_GEMMFR");
-  return e ? atoi(e) != 0 : M / 256 >= 64;
+  return e ? atoi(e) != 0 : M / 256 >= 64;    // (a minimum K of 1024 instead of 192 measured the same on the compacted student and 0.5 % less on the dense one)
 }
 
 extern "C" int devit_set_reserved_cus(int n) {

@@ -193,7 +193,7 @@ class Block(nn.Module):
             bp.qkv_w = bp.proj_w = bp.fc1_w = bp.fc2_w = None
             bp.qkv_b, bp.proj_b, bp.fc1_b, bp.fc2_b = c["qkv_b"], self.attn.proj.bias, c["fc1_b"], self.mlp.fc2.bias
             bp.qkv_w16, bp.proj_w16, bp.fc1_w16, bp.fc2_w16 = c["qkv_w16"], c["proj_w16"], c["fc1_w16"], c["fc2_w16"]
-            bp.fc2_w16t = None
+            bp.fc2_w16t = c.get("fc2_w16t")
             bp.num_heads, bp.neuron_gate = c["num_heads"], None
             bp.head_gate = None if c.get("heads_compacted", True) else self.attn.gate_on(device)
             bp.dp_prob, bp.module, bp.compacted = (self.drop_prob if self.training else 0.), self, True

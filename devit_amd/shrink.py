@@ -108,6 +108,10 @@ def compact(model, trainable=False):
                             serial=_serial[0] * 100 + len(report),
                             heads_compacted=heads,
                             neurons_idx=w["kept_neurons"].to(dev))
+        c = blk._compact
+        if c["fc2_w16"].is_cuda and c["fc2_w16"].shape[0] == 384:      # fc2's forward on the full-row GEMM (csrc/gemm.hip): k-major copy
+            c["fc2_w16t"] = torch.empty((c["fc2_w16"].shape[1], 384), dtype=c["fc2_w16"].dtype, device=dev)
+            ops.transpose16(c["fc2_w16"], c["fc2_w16t"])
         report.append((len(w["kept_heads"]), w["num_heads"], len(w["kept_neurons"]), w["fc1_w"].shape[0]))
     return report
 
@@ -200,8 +204,13 @@ def refresh_blocks(blocks):
                      _job(qb, c["qkv_b"], m["qkv_rows"], 3 * Hr * 64, 1, 1, 1, 0, 4),
                      _job(f1b, c["fc1_b"], m["neurons"], Nr, 1, 1, 1, 0, 4)]
             keep.append((q16, p16, f1, f2, qb, f1b, m))
-        tab = owner["refresh_table"] = (key, _JobTable(jobs, keep, owner["qkv_w16"].device))
+        # (second launch, behind the gathers: the k-major copies of the compact fc2 weights the full-row GEMM reads, ops._Transposes)
+        tr = ops._Transposes([(c["fc2_w16"], c["fc2_w16t"]) for _, c in todo if c.get("fc2_w16t") is not None]) \
+            if any(c.get("fc2_w16t") is not None for _, c in todo) else None
+        tab = owner["refresh_table"] = (key, _JobTable(jobs, keep, owner["qkv_w16"].device), tr)
     tab[1].run()
+    if tab[2] is not None:
+        tab[2].run()
 
 
 def attach_training(blk, bp, c):

@@ -318,6 +318,46 @@ def test_full_row_gemm_inside_the_model_full_size(dev, monkeypatch):
     assert torch.equal(a, b)
 
 
+def test_full_row_gemm_through_compacted_blocks_full_size(dev, monkeypatch):
+    """The same identity for a physically shrunk student (shrink.compact(trainable=True), 0.3 / 0.3 gates): the compact fc2 weight [384][1152]
+    gets its k-major copy behind every re-gather (a second launch), fc1's dgrad runs at K = 1152 and qkv's at K = 768 on the full-row kernel."""
+    import devit_amd
+    from devit_amd import shrink
+    torch.manual_seed(6)
+    s = devit_amd.create_model("dedeit", num_classes=25, drop_path_rate=0.0).to(dev).train()
+    gen = torch.Generator().manual_seed(7)
+    for blk in s.blocks:
+        hm, nm = torch.ones(6), torch.ones(1536)
+        hm[torch.randperm(6, generator=gen)[:2]] = 0
+        nm[torch.randperm(1536, generator=gen)[:461]] = 0
+        blk.attn.gate, blk.mlp.gate = hm, nm
+    shrink.compact(s, trainable=True)
+    try:
+        assert s.blocks[0]._compact["fc2_w16t"].shape == (1152, 384)
+        g = torch.Generator(device=dev).manual_seed(33)
+        img = torch.randn((B, 3, 224, 224), generator=g, device=dev)
+
+        def run(flag):
+            monkeypatch.setenv("DEVIT_GEMMFR", flag)
+            for p in s.parameters():
+                p.grad = None
+            out = s(img, output_qkv=True)
+            lg = out["output"][0]
+            (lg.float().square().mean() + out["qkv"][5][2].float().square().mean()).backward()
+            torch.cuda.synchronize()
+            return lg.detach().clone(), s.pos_embed.grad.detach().clone()
+
+        ref, got = run("0"), run("1")
+        assert torch.equal(ref[0], got[0])
+        assert float((ref[1] - got[1]).abs().max()) <= 1e-5 * float(ref[1].abs().max())
+        with torch.no_grad():                      # move a master: the next forward re-gathers AND re-transposes
+            s.blocks[3].mlp.fc2.weight.mul_(1.25)
+        ref, got = run("0"), run("1")
+        assert torch.equal(ref[0], got[0])
+    finally:
+        shrink.uncompact(s)
+
+
 def test_ensemble_config5_full_size(dev):
     """BASELINE config 5 at its size: four `dedeit` sub-models (250 classes each, shrink_ratio 0.3 head / neuron gates) +
     EnsMLP -> 1000 classes, bs 256, inference (ensemble.py; models/ensemble_models.py:32-40).  The 4 x 25-class, bs-4 form is
