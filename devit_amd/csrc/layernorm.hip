@@ -30,16 +30,20 @@ __device__ __forceinline__ size_t ln_in_row(int r, int group, int stride) {
 // NV = D / 128 of them; bf16 output leaves as 8-byte stores.  (The first version read float2 per lane with one wave
 // per row: 2.6-3.1 TB/s from cold HBM, tools/ln_cold.py.)  Statistics: two-pass (mean, then centred sum of squares)
 // in fp32, reduced over the 32 lanes by xor shuffles.
-template <int NV>
+// RAG: D is a multiple of 4 but not of 128 (D = 192: the three narrow registered geometries, which run on the exact-fp32 path): NV = ceil(D / 128), lanes
+// whose float4 lies past D hold zeros and store nothing.
+template <int NV, bool RAG = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
   const int lane = threadIdx.x & 63, l32 = lane & 31, sub = lane >> 5;
   const int half_global = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + sub;
   const int nhalves = gridDim.x * 8;
   f32x4 gm[NV], bt[NV];
+  bool ok[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    gm[v] = *(const f32x4*)(a.gamma + (v * 32 + l32) * 4);
-    bt[v] = *(const f32x4*)(a.beta + (v * 32 + l32) * 4);
+    ok[v] = !RAG || (v * 32 + l32) * 4 < a.D;
+    gm[v] = ok[v] ? *(const f32x4*)(a.gamma + (v * 32 + l32) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    bt[v] = ok[v] ? *(const f32x4*)(a.beta + (v * 32 + l32) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const float invD = 1.0f / (float)a.D;
   // both halves of a wave run the same number of trips (the shuffles need every lane): a half past the end redoes
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      xv[v] = load_stream((const f32x4*)(xr + (v * 32 + l32) * 4));
+      xv[v] = ok[v] ? load_stream((const f32x4*)(xr + (v * 32 + l32) * 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
       s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
     }
 #pragma unroll
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     for (int v = 0; v < NV; ++v) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float d = xv[v][e] - mu;
+        const float d = ok[v] ? xv[v][e] - mu : 0.f;
         q = fmaf(d, d, q);
       }
     }
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     for (int v = 0; v < NV; ++v) {
       const f32x4 y = (xv[v] - mu) * rs * gm[v] + bt[v];
       const size_t o = (size_t)r * a.D + (v * 32 + l32) * 4;
+      if (RAG && !ok[v]) continue;
       if (a.y_bf16) *(bf16x4*)(a.y_bf16 + o) = a.f16 ? cvt4<true>(y) : cvt4<false>(y);
       if (a.y_f32) *(f32x4*)(a.y_f32 + o) = y;
     }
@@ -104,16 +109,18 @@ struct LnBwdArgs {
 
 // Half a wave (32 lanes x 4*NV columns) per token row, two rows per wave pass: 16-byte loads of x / dres and 8-byte
 // loads of the bf16 dy keep ~2.5 KB per wave in flight (HBM-bound kernel).
-template <int NV>
+template <int NV, bool RAG = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   __shared__ float red[4][3][NV * 128];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
   const int slot = (blockIdx.x * 4 + wv) * 2 + half;       // half-wave id
   const int nslots = gridDim.x * 8;
   f32x4 gm[NV], dg[NV], db[NV], dsum[NV];
+  bool ok[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    gm[v] = *(const f32x4*)(a.gamma + v * 128 + hl * 4);
+    ok[v] = !RAG || v * 128 + hl * 4 < a.D;
+    gm[v] = ok[v] ? *(const f32x4*)(a.gamma + v * 128 + hl * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dsum[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
       const int c = v * 128 + hl * 4;
       f32x4 xv = {0.f, 0.f, 0.f, 0.f};
       dyv[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (live) {
+      if (live && ok[v]) {
         xv = load_stream((const f32x4*)(xr + c));
         if (a.dy_is_f32) {
           dyv[v] = load_stream((const f32x4*)((const float*)a.dy + (size_t)r * a.D + c));
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
           dyv[v] = (f32x4){bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
         }
       }
-      xh[v] = (xv - mu) * rs;
+      xh[v] = ok[v] ? (xv - mu) * rs : (f32x4){0.f, 0.f, 0.f, 0.f};
       g[v] = dyv[v] * gm[v];
       dg[v] += dyv[v] * xh[v];
       db[v] += dyv[v];
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const size_t o = pr * a.D + v * 128 + hl * 4;
+        if (RAG && !ok[v]) continue;
         f32x4 d = rs * (g[v] - m1 - xh[v] * m2);
         if (a.dres) d += load_stream((const f32x4*)(a.dres + o));
         *(f32x4*)(a.dx + o) = d;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
       db[v][e] += __shfl_xor(db[v][e], 32, 64);
       dsum[v][e] += __shfl_xor(dsum[v][e], 32, 64);
     }
-    if (half == 0) {
+    if (half == 0 && ok[v]) {
       *(f32x4*)&red[wv][0][v * 128 + hl * 4] = dg[v];
       *(f32x4*)&red[wv][1][v * 128 + hl * 4] = db[v];
       *(f32x4*)&red[wv][2][v * 128 + hl * 4] = dsum[v];
@@ -222,13 +230,21 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* part
 
 template <typename Args, typename F>
 int dispatch_nv(int D, F&& f) {
+  if (D % 128) {         // narrow geometries (D = 192): ceil(D / 128) vectors per lane, the last one ragged
+    switch ((D + 127) / 128) {
+      case 1: f(std::integral_constant<int, 1>(), std::true_type()); return 0;
+      case 2: f(std::integral_constant<int, 2>(), std::true_type()); return 0;
+      case 3: f(std::integral_constant<int, 3>(), std::true_type()); return 0;
+      default: return -1;
+    }
+  }
   switch (D / 128) {
-    case 1: f(std::integral_constant<int, 1>()); return 0;
-    case 2: f(std::integral_constant<int, 2>()); return 0;
-    case 3: f(std::integral_constant<int, 3>()); return 0;
-    case 4: f(std::integral_constant<int, 4>()); return 0;
-    case 6: f(std::integral_constant<int, 6>()); return 0;
-    case 8: f(std::integral_constant<int, 8>()); return 0;
+    case 1: f(std::integral_constant<int, 1>(), std::false_type()); return 0;
+    case 2: f(std::integral_constant<int, 2>(), std::false_type()); return 0;
+    case 3: f(std::integral_constant<int, 3>(), std::false_type()); return 0;
+    case 4: f(std::integral_constant<int, 4>(), std::false_type()); return 0;
+    case 6: f(std::integral_constant<int, 6>(), std::false_type()); return 0;
+    case 8: f(std::integral_constant<int, 8>(), std::false_type()); return 0;
     default: return -1;
   }
 }
@@ -240,12 +256,12 @@ extern "C" int devit_layernorm_fwd(const float* x, int rows, int D, int in_group
                                    float* mean, float* rstd, int dtype16, void* stream) {
   DEVIT_CHECK(x && gamma && beta && (y_bf16 || y_f32), DEVIT_ERR_ARG, "devit_layernorm_fwd: null pointer");
   DEVIT_CHECK(dtype16 == 0 || dtype16 == 1, DEVIT_ERR_ARG, "devit_layernorm_fwd: dtype16 must be 0 (bf16) or 1 (f16)");
-  DEVIT_CHECK(rows > 0 && D % 128 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE,
-              "devit_layernorm_fwd: D=%d must be a multiple of 128, <= 1024", D);
+  DEVIT_CHECK(rows > 0 && D > 0 && D % 64 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE,
+              "devit_layernorm_fwd: D=%d must be a multiple of 64 (of 128 above 384), <= 1024", D);
   LnFwdArgs a{x, gamma, beta, (__bf16*)y_bf16, y_f32, mean, rstd, rows, D, in_group, in_stride, eps, dtype16};
   const int grid = rows < 8 * 2048 ? (rows + 7) / 8 : 2048;   // 8 half-waves (rows in flight) per 256-thread block
-  int rc = dispatch_nv<LnFwdArgs>(D, [&](auto nv) {
-    hipLaunchKernelGGL((ln_fwd_kernel<decltype(nv)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  int rc = dispatch_nv<LnFwdArgs>(D, [&](auto nv, auto rag) {
+    hipLaunchKernelGGL((ln_fwd_kernel<decltype(nv)::value, decltype(rag)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   });
   DEVIT_CHECK(rc == 0, DEVIT_ERR_SHAPE, "devit_layernorm_fwd: unsupported D=%d", D);
   DEVIT_LAUNCH_CHECK();
@@ -265,7 +281,7 @@ extern "C" int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x
                                    int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   DEVIT_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, DEVIT_ERR_ARG,
               "devit_layernorm_bwd: null pointer");
-  DEVIT_CHECK(rows > 0 && D % 128 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: D=%d", D);
+  DEVIT_CHECK(rows > 0 && D > 0 && D % 64 == 0 && D <= LN_MAX_NV * 128, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: D=%d", D);
   DEVIT_CHECK(workspace_bytes >= devit_layernorm_bwd_workspace(rows, D), DEVIT_ERR_ARG,
               "devit_layernorm_bwd: workspace too small");
   DEVIT_CHECK(!rowscale || rows_per_scale > 0, DEVIT_ERR_ARG, "devit_layernorm_bwd: rows_per_scale");
@@ -273,8 +289,8 @@ extern "C" int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x
   const int grid = ln_bwd_grid(rows);
   LnBwdArgs a{dy, x, mean, rstd, gamma, dres, dx, (__bf16*)dx_bf16, rowscale, rows_per_scale,
               (float*)workspace, rows, D, in_group, in_stride, dy_is_f32};
-  int rc = dispatch_nv<LnBwdArgs>(D, [&](auto nv) {
-    hipLaunchKernelGGL((ln_bwd_kernel<decltype(nv)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  int rc = dispatch_nv<LnBwdArgs>(D, [&](auto nv, auto rag) {
+    hipLaunchKernelGGL((ln_bwd_kernel<decltype(nv)::value, decltype(rag)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   });
   DEVIT_CHECK(rc == 0, DEVIT_ERR_SHAPE, "devit_layernorm_bwd: unsupported D=%d", D);
   DEVIT_LAUNCH_CHECK();

@@ -403,8 +403,29 @@ class VisionTransformer(nn.Module):
         # "bf16": the training path.  "f16": the same kernels with IEEE f16 operands / stored activations, forward only --
         # for frozen teachers (DeiT-B logits 1.1e-3 from fp32 instead of 6.8e-3; step 1.4 % slower: both measured).  "f32": exact-fp32 parity
         # path (ops_f32.py), not tuned
+        self._pinned_precision = None
         self.precision = "bf16"
         self.init_weights(weight_init)
+
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value not in ("bf16", "f16", "f32"):
+            raise ValueError(f"precision {value!r}: one of 'bf16', 'f16', 'f32'")
+        pinned = getattr(self, "_pinned_precision", None)
+        if pinned is not None and value != pinned:
+            raise L.DevitError(f"this geometry (embed_dim {self.embed_dim}) runs on the exact-fp32 kernels only: precision is pinned to "
+                               f"{pinned!r} (de_vit.check_geometry)")
+        self._precision = value
+
+    def pin_precision(self, value):
+        """Fix the kernel family this model runs on (narrow geometries: "f32")."""
+        self._pinned_precision = None
+        self.precision = value
+        self._pinned_precision = value
 
     # ---- init / bookkeeping identical to the reference (de_vit.py:205-240) ------------------------------
     def init_weights(self, mode=''):
@@ -530,17 +551,19 @@ model_config = {
 
 def check_geometry(name, embed_dim, num_heads, mlp_ratio=4.):
     """Refuse, at construction and with the reason, a geometry the gfx950 kernels are not built for -- instead of registering a
-    name whose first forward fails deep inside a launch.  The GEMM tiles want every Linear's output width in multiples of 128
-    (csrc/gemm.hip), LayerNorm and the block calls a width in multiples of 128 (csrc/layernorm.hip, encoder.hip), attention
-    64-wide heads (csrc/attention.hip).  Of the names models/deit_vit.py:457-525 registers this excludes the three D = 192 ones
-    (`deit_tiny_patch16_224`, `deit_tiny_distilled_patch16_224`, `vit_tiny_patch16_224`): none of them is on the DeViT path
-    (student `dedeit` is 384 / 6, teachers are DeiT-B 768 / 12 or ViT-L 1024 / 16; README.md:50-68 of the reference)."""
+    name whose first forward fails deep inside a launch.  Heads are 64 wide everywhere (csrc/attention.hip and the reference's own
+    registered names).  The MFMA GEMM tiles, the fused attention kernels and the block calls want every width in multiples of 128
+    (csrc/gemm.hip, encoder.hip): geometries that are multiples of 64 only -- the three D = 192 names of models/deit_vit.py:457-525
+    (`deit_tiny_patch16_224`, `deit_tiny_distilled_patch16_224`, `vit_tiny_patch16_224`; none of them is on the DeViT path: student
+    `dedeit` is 384 / 6, teachers are DeiT-B 768 / 12 or ViT-L 1024 / 16, README.md:50-68 of the reference) -- run on the exact-fp32
+    kernels instead (csrc/sgemm.hip, ops_f32.py: forward, backward, every loss; a few TFLOP/s, which a 1.3-GFLOP model does not notice):
+    their `precision` is pinned to "f32".  Returns True for such a narrow geometry."""
     hidden = int(embed_dim * mlp_ratio)
-    if embed_dim % 128 or embed_dim != num_heads * 64 or hidden % 128:
+    if embed_dim % 64 or embed_dim != num_heads * 64 or hidden % 64 or embed_dim > 1024:
         raise NotImplementedError(
             f"{name}: embed_dim={embed_dim}, num_heads={num_heads}, hidden={hidden} is not a geometry the MI355X kernels are built "
-            f"for (embed_dim and hidden must be multiples of 128, heads 64 wide); supported registered names: "
-            f"{[n for n, c in model_config.items() if c['embed_dim'] % 128 == 0]}")
+            f"for (embed_dim and hidden must be multiples of 64, heads 64 wide, embed_dim <= 1024); registered names: {list(model_config)}")
+    return bool(embed_dim % 128 or hidden % 128)
 
 
 def _cfg(**kwargs):
@@ -552,8 +575,10 @@ def _cfg(**kwargs):
 def _make(name):
     def fn(pretrained=False, pretrained_path=None, **kwargs):
         geo = {**model_config[name], **kwargs}
-        check_geometry(name, geo.get('embed_dim', 768), geo.get('num_heads', 12), geo.get('mlp_ratio', 4.))
+        narrow = check_geometry(name, geo.get('embed_dim', 768), geo.get('num_heads', 12), geo.get('mlp_ratio', 4.))
         model = VisionTransformer(**geo)
+        if narrow:
+            model.pin_precision("f32")
         model.default_cfg = _cfg()
         if pretrained_path is not None and pretrained:
             ckpt = torch.load(pretrained_path, map_location='cpu', weights_only=False)

@@ -83,6 +83,8 @@ def relation_losses_packed(student_qkv, teacher_qkv):
         from . import ops_f32
         losses = ops_f32.RelationLossF32Fn.apply(s_buf, t_buf.detach().float(), B, N, hd_s, hd_t)
         return losses[0], losses[1], losses[2]
+    if t_buf.dtype == torch.float32:          # (an fp32-path teacher under a 16-bit student: the generic per-feature form repacks it)
+        return tuple(feature_relation_loss(tv, sv) for sv, tv in zip(student_qkv, teacher_qkv))
     losses = ops.RelationLossFn.apply(s_buf, t_buf.detach(), B, N, hd_s, hd_t)
     return losses[0], losses[1], losses[2]
 
@@ -100,6 +102,8 @@ def relation_losses_vector(student_qkv, teacher_qkv):
     if s_buf.dtype == torch.float32:          # exact-fp32 parity path
         from . import ops_f32
         return ops_f32.RelationLossF32Fn.apply(s_buf, t_buf.detach().float(), B, N, hd_s, hd_t)
+    if t_buf.dtype == torch.float32:
+        return None                           # (the caller falls back to relation_losses_packed's generic form)
     return ops.RelationLossFn.apply(s_buf, t_buf.detach(), B, N, hd_s, hd_t)
 
 

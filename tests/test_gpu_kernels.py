@@ -345,7 +345,7 @@ def test_gemm_batched_and_patch(dev):
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("D", [384, 768])
+@pytest.mark.parametrize("D", [384, 768, 192])
 def test_layernorm(dev, D):
     from devit_amd import ops
     M = 1000

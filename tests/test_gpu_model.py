@@ -546,6 +546,75 @@ def test_vit_large_teacher_forward_vs_oracle(dev):
     assert torch.equal(plain, out["output"])
 
 
+@pytest.mark.parametrize("name", ["deit_tiny_patch16_224", "deit_tiny_distilled_patch16_224", "vit_tiny_patch16_224"])
+def test_narrow_names_forward_vs_oracle(dev, name):
+    """The three D = 192 names of models/deit_vit.py:457-525 (3 heads, hidden 768): not a geometry of the MFMA tiles, so they are pinned to the
+    exact-fp32 kernels (de_vit.check_geometry) -- and therefore held to the fp32 bar: eval logits and q / k / v of block 5 within 1e-4 of the
+    CPU oracle, top-1 exact, the return-type matrix of models/de_vit.py:316-334."""
+    import devit_amd
+    geom = O.GEOMETRY[name]
+    st = O.make_state(geom, C, "N")
+    m = devit_amd.create_model(name, num_classes=C).to(dev).eval()
+    m.load_state_dict(st)
+    assert m.precision == "f32" and m.embed_dim == 192 and [k for k in m.state_dict()] == list(st)
+    img = torch.from_numpy(det_array("narrow", (4, 3, 224, 224), std=0.7))
+    ntok = 2 if geom["distilled"] else 1
+    with torch.no_grad():
+        ref = O.forward(st, geom, img, training=False)
+        out = m(img.to(dev), output_qkv=True)
+        plain = m(img.to(dev))
+    assert out["output"].shape == (4, C) and torch.equal(plain, out["output"])
+    assert chk(rel(out["output"], ref["output"].numpy()), 1e-4)
+    assert torch.equal(out["output"].argmax(1).cpu(), ref["output"].argmax(1))
+    for got, want in zip(out["qkv"][5], ref["qkv"][5]):
+        assert got.shape == (4, 3, 196 + ntok, 64) and chk(rel(got, want.numpy()), 1e-4)
+
+
+def test_narrow_student_distill_step_vs_oracle(dev):
+    """One DEKD step (engine.py:68-127) with `deit_tiny_distilled_patch16_224` as the STUDENT under the DeiT-B teacher's bf16 kernels, bs 8,
+    recorded DropPath masks: five losses within 2e-2 of the oracle (the teacher side carries bf16 rounding: test_distill_step_vs_golden's bar),
+    every gradient norm within 2e-2.  With the teacher on the fp32 path too (precision="f32"): losses 1e-4, gradient norms 1e-3."""
+    import devit_amd
+    from devit_amd import engine
+    gs, gt = O.GEOMETRY["deit_tiny_distilled_patch16_224"], O.GEOMETRY["deit_base_distilled_patch16_224"]
+    st_s, st_t = O.make_state(gs, C, "NS"), O.make_state(gt, C, "T")
+    s = devit_amd.create_model("deit_tiny_distilled_patch16_224", num_classes=C, drop_path_rate=0.1, drop_block_rate=None)
+    t = devit_amd.create_model("deit_base_distilled_patch16_224", num_classes=C)
+    s.load_state_dict(st_s)
+    t.load_state_dict(st_t)
+    s.to(dev).train()
+    t.to(dev).eval()
+    for p in t.parameters():
+        p.requires_grad_(False)
+    img = torch.from_numpy(det_array("narrow_step", (8, 3, 224, 224), std=0.8))
+    g = torch.Generator().manual_seed(11)
+    y = torch.randint(0, C, (8,), generator=g)
+    soft = torch.full((8, C), 0.1 / C).scatter_(1, y[:, None], 0.9 + 0.1 / C)
+    keep = 1.0 - torch.linspace(0, 0.1, 12)
+    sc = torch.floor(keep.view(12, 1, 1) + torch.rand((12, 2, 8), generator=g)) / keep.view(12, 1, 1)
+    masks = [(sc[i, 0].contiguous(), sc[i, 1].contiguous()) for i in range(12)]
+    params = {k: v.clone().requires_grad_(True) for k, v in st_s.items()}
+    ref = O.distill_step(params, gs, st_t, gt, img, soft, dp_scales=masks)
+    ref["loss"].backward()
+    names = list(params)
+    nref = torch.stack([params[n].grad.norm() for n in names])
+    for tprec, lbar, gbar in (("bf16", 2e-2, 2e-2), ("f32", 1e-4, 1e-3)):
+        t.precision = tprec
+        for p in s.parameters():
+            p.grad = None
+        out = engine.distill_forward(s, t, img.to(dev), soft.to(dev), gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0,
+                                     dp_scales=[(a.to(dev), b.to(dev)) for a, b in masks])
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        for k in ("loss", "cls_loss", "q_loss", "k_loss", "v_loss"):
+            e = abs(float(out[k].detach()) - float(ref[k].detach())) / abs(float(ref[k].detach()))
+            assert chk(e, lbar), (tprec, k, float(out[k].detach()), float(ref[k].detach()))
+        got = dict(s.named_parameters())
+        nhip = torch.stack([got[n].grad.float().norm().cpu() for n in names])
+        assert chk(float(((nhip - nref).abs() / (nref + 1e-3 * nref.max())).max()), gbar), tprec
+    t.precision = "bf16"
+
+
 # ------------------------------------------------------------------------------------------ batch-size edges
 def test_batch_invariance_and_ragged_batches(models, dev):
     """Ragged inputs: batch sizes that fill no tile (1, 3, 19 images = 198 / 594 / 3762 token rows), changing from call

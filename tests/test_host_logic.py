@@ -23,13 +23,19 @@ def test_registry_semantics():
     assert m.num_classes == 25 and m.embed_dim == 384 and len(m.blocks) == 12
     assert de_vit.model_config["dedeit"]["embed_dim"] == 384
     assert de_vit.model_config["deit_base_distilled_patch16_224"]["embed_dim"] == 768
-    # every registered name either runs or refuses AT CONSTRUCTION with the reason (the D = 192 names of models/deit_vit.py:457-525
-    # do not fit the kernels' tiles; nothing on the DeViT path uses them)
+    # every registered name constructs; the D = 192 names of models/deit_vit.py:457-525 do not fit the MFMA kernels' tiles and are pinned to the
+    # exact-fp32 kernels (de_vit.check_geometry); anything that is not 64-wide heads x a multiple of 64 refuses AT CONSTRUCTION with the reason
     for name in ("deit_tiny_patch16_224", "deit_tiny_distilled_patch16_224", "vit_tiny_patch16_224"):
-        with pytest.raises(NotImplementedError, match="multiples of 128"):
-            registry.create_model(name, num_classes=10)
+        m = registry.create_model(name, num_classes=10)
+        assert m.embed_dim == 192 and m.blocks[0].attn.num_heads == 3 and m.precision == "f32"
+        with pytest.raises(Exception, match="pinned"):
+            m.precision = "bf16"
+    assert registry.create_model("dedeit", num_classes=10).precision == "bf16"
+    assert registry.create_model("dedeit", embed_dim=320, num_heads=5, num_classes=10).precision == "f32"      # (5 heads x 64: narrow, fp32 kernels)
+    with pytest.raises(NotImplementedError, match="multiples of 64"):
+        registry.create_model("dedeit", embed_dim=320, num_heads=4)                                            # heads are not 64 wide
     with pytest.raises(NotImplementedError):
-        registry.create_model("dedeit", embed_dim=320, num_heads=5)
+        registry.create_model("dedeit", embed_dim=160, num_heads=2)
 
 
 def test_statedict_abi():
