@@ -4,6 +4,7 @@
 // of 1024 / PIECE rows per request, K-steps of PIECE bytes.  PIECE = 128 is what every BK = 64 kernel of gemm.hip does.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+// (the 16-requests-in-flight rows of the first version, profiles/r05_a_gemm_full_row.txt, measured the same as 8)
 #include <vector>
 #include <algorithm>
 #define LDS_PTR(p) ((__attribute__((address_space(3))) char*)(p))
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void stream(const char* A, int K, int panels, 
     for (int ks = 0; ks < ksteps; ++ks)
       for (int rg = 0; rg < row_groups; ++rg) {
         const int row = (rg * 4 + wave) * RPR + lane / LPR;
-        dma1(base + (size_t)row * rowb + (size_t)ks * PIECE + (lane % LPR) * 16, lds + (unsigned)(wave * 32 + (slot & 31)) * 1024u);
+        dma1(base + (size_t)row * rowb + (size_t)ks * PIECE + (lane % LPR) * 16, lds + (unsigned)(wave * 8 + (slot & 7)) * 1024u);
         ++slot;
         wait_vmcnt<INFLIGHT - 1>();
       }
@@ -45,20 +46,20 @@ __global__ __launch_bounds__(256) void stream(const char* A, int K, int panels, 
 }
 
 template <int PIECE, int INFLIGHT>
-void run(const char* A, size_t M, int K, char* flush, size_t flush_bytes, unsigned long long* dout) {
-  hipFuncSetAttribute((const void*)stream<PIECE, INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+void run(const char* A, size_t M, int K, char* flush, size_t flush_bytes, unsigned long long* dout, int wgs_per_cu = 1) {
+  static_assert(INFLIGHT <= 8, "8 LDS slots per wave");
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
   for (int rep = 0; rep < 2; ++rep) {
     hipMemset(flush, rep, flush_bytes); hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((stream<PIECE, INFLIGHT>), dim3(256), dim3(256), 128 * 1024, 0, A, K, (int)(M / 256), dout);
+    hipLaunchKernelGGL((stream<PIECE, INFLIGHT>), dim3(256 * wgs_per_cu), dim3(256), 32 * 1024, 0, A, K, (int)(M / 256), dout);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     best = std::min(best, ms);
   }
-  printf("K %5d (row stride %5d B)  piece %4d B x %2d rows per request, %2d requests in flight per wave (%3d KB per CU): %7.1f us  %5.2f TB/s\n", K, K * 2, PIECE,
-         1024 / PIECE, INFLIGHT, INFLIGHT * 4, best * 1e3, (double)M * K * 2 / (best * 1e-3) / 1e12);
+  printf("K %5d (row stride %5d B)  piece %4d B x %2d rows per request, %2d requests in flight per wave, %d workgroups of 4 waves per CU (%3d KB per CU): %7.1f us  %5.2f TB/s\n", K, K * 2, PIECE,
+         1024 / PIECE, INFLIGHT, wgs_per_cu, INFLIGHT * 4 * wgs_per_cu, best * 1e3, (double)M * K * 2 / (best * 1e-3) / 1e12);
 }
 
 int main() {
@@ -66,14 +67,20 @@ int main() {
   char *A, *flush; unsigned long long* dout;
   hipMalloc(&A, bytes); hipMalloc(&flush, (size_t)512 << 20); hipMalloc(&dout, 256 * 8);
   hipMemset(A, 1, bytes); hipDeviceSynchronize();
+  hipMalloc(&dout, 1024 * 8);
   for (int K : {384, 1536, 3072}) {
     const size_t M = bytes / ((size_t)K * 2) / 256 * 256;
     run<128, 8>(A, M, K, flush, (size_t)512 << 20, dout);
-    run<128, 16>(A, M, K, flush, (size_t)512 << 20, dout);
     run<256, 8>(A, M, K, flush, (size_t)512 << 20, dout);
     run<512, 8>(A, M, K, flush, (size_t)512 << 20, dout);
     if (K * 2 >= 1024) run<1024, 8>(A, M, K, flush, (size_t)512 << 20, dout);
-    if (K * 2 >= 1024) run<1024, 16>(A, M, K, flush, (size_t)512 << 20, dout);
+  }
+  // more waves per CU (attention runs 16): does the stream go faster?
+  for (int w : {1, 2, 4}) {
+    const int K = 1152;      // the qkv row of the student (2304 B): a head slice is 128 B of it
+    const size_t M = bytes / ((size_t)K * 2) / 256 * 256;
+    run<128, 4>(A, M, K, flush, (size_t)512 << 20, dout, w);
+    run<128, 8>(A, M, K, flush, (size_t)512 << 20, dout, w);
   }
   return 0;
 }
