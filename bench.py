@@ -511,7 +511,8 @@ def main():
     busy, busy_src = committed_counter("*_pmc_mfma.json", "mfma_busy")
     from devit_amd import de_vit
     executed = GFLOP_PER_IMG_EXECUTED if de_vit.LEAN_TAIL else GFLOP_PER_IMG_STEP
-    roof = {"bound": "mfma", "kernel": "gemm_kernel<*, A_row, B_row, *> (persistent 128x128 / 256x256 x64 bf16 MFMA tiles; fwd Linear layers of teacher + student)",
+    roof = {"bound": "mfma", "kernel": "gemm_kernel<*, A_row, B_row, *> (persistent 128x128 / 256x256 x64 bf16 MFMA tiles; fwd Linear layers of teacher + student; "
+                      "the student's fc2 on the full-row 256x384 kernel through a k-major copy of its weight counts here too)",
             "achieved": round(fl / tm / 1e12, 2), "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
             "frac": round(fl / tm / BF16_DENSE_PEAK, 4),
             "achieved_counts": "FLOPs the launches execute (2 M N K of each launch, padded rows included) / their event time",

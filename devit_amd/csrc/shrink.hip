@@ -16,8 +16,27 @@ __global__ __launch_bounds__(256) void index_copy_kernel(const devit_index_job* 
     const int tr = (j.rows + 63) / 64, tc = (j.cols + 63) / 64;
     const unsigned short* src = (const unsigned short*)j.src;
     unsigned short* dst = (unsigned short*)j.dst;
+    const bool pairs = ((j.rows | j.cols | j.src_ld | j.dst_ld) & 1) == 0 && (((size_t)j.src | (size_t)j.dst) & 3) == 0;   // 4-byte accesses
     for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
       const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+      if (pairs) {
+        for (int e = threadIdx.x; e < 2048; e += 256) {
+          const int r = e >> 5, c = (e & 31) * 2;
+          if (r0 + r < j.rows && c0 + c < j.cols) {
+            const unsigned v = *(const unsigned*)(src + (long long)(r0 + r) * j.src_ld + c0 + c);
+            tile[r][c] = (unsigned short)v;
+            tile[r][c + 1] = (unsigned short)(v >> 16);
+          }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2048; e += 256) {
+          const int c = e >> 5, r = (e & 31) * 2;
+          if (r0 + r < j.rows && c0 + c < j.cols)
+            *(unsigned*)(dst + (long long)(c0 + c) * j.dst_ld + r0 + r) = (unsigned)tile[r][c] | ((unsigned)tile[r + 1][c] << 16);
+        }
+        __syncthreads();
+        continue;
+      }
       for (int e = threadIdx.x; e < 4096; e += 256) {
         const int r = e >> 6, c = e & 63;
         if (r0 + r < j.rows && c0 + c < j.cols) tile[r][c] = src[(long long)(r0 + r) * j.src_ld + c0 + c];

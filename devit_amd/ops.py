@@ -98,7 +98,7 @@ class _Transposes:
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(pairs[0][0].device)
         self.keep, self.n = pairs, len(jobs)
         self.key = tuple((s_.data_ptr(), d.data_ptr()) for s_, d in pairs)
-        self.blocks = max(1, min(64, max((s_.shape[0] + 63) // 64 * ((s_.shape[1] + 63) // 64) for s_, _ in pairs)))
+        self.blocks = max(1, min(144, max((s_.shape[0] + 63) // 64 * ((s_.shape[1] + 63) // 64) for s_, _ in pairs)))   # one 64 x 64 tile per block
 
     def run(self):
         call("devit_index_copy", ptr(self.table), self.n, self.blocks, stream_ptr())
@@ -117,7 +117,9 @@ def _profiled_gemm(kw):
         e0.record()
         gemm(**kw)
         e1.record()
-        rec.append((("A_km" if kw["a_km"] else "A_row") + "/" + ("B_km" if kw["b_km"] else "B_row"), kw["M"], kw["N"],
+        # (the student's fc2 forward reads a k-major COPY of its weight on the full-row kernel: still a forward Linear layer of the dominant template)
+        fwd_kmajor_copy = kw["b_km"] and kw["kind"] == L.EPI_RESIDUAL_F32
+        rec.append((("A_km" if kw["a_km"] else "A_row") + "/" + ("B_km" if kw["b_km"] and not fwd_kmajor_copy else "B_row"), kw["M"], kw["N"],
                     kw["K"], kw["batch"], e0, e1))
     finally:
         PROFILE = rec

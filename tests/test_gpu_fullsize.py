@@ -32,7 +32,9 @@ def ints(shape, lo, hi, dev, seed):
 # shape with a plain fp32 store, and fc1's shape: 256x256-tile launches of 2.32 and 9.28 rounds on 256 CUs.
 @pytest.mark.parametrize("Nout,K,kind,bkm", [
     (1152, 384, "f32", 0), (2304, 768, "bf16", 0), (768, 3072, "res", 0), (384, 1536, "f32", 1), (1536, 384, "bf16", 0),
-    (768, 3072, "res_noscale", 0), (768, 3072, "f32", 0), (3072, 768, "bf16", 0)])
+    (768, 3072, "res_noscale", 0), (768, 3072, "f32", 0), (3072, 768, "bf16", 0),
+    # the full-row 256x384 kernel (k-major weight, N = 384): qkv's dgrad shape with the bf16 store, fc2's forward with the residual epilogue
+    (384, 1152, "bf16", 1), (384, 1536, "res", 1)])
 def test_gemm_exact_integers_full_size(dev, Nout, K, kind, bkm):
     """A in {-3..3}, W in {-1,0,1}: |sum| <= 3 K < 2^14, exact in fp32 and (for the bf16 store: values clipped to
     |x| <= 256 by construction of a sparse W) in bf16 -- every output tile of the persistent launch, bit for bit."""
@@ -64,7 +66,7 @@ def test_gemm_exact_integers_full_size(dev, Nout, K, kind, bkm):
         res = ints((M, Nout), -50, 50, dev, 4).float()
         rs = ints((B,), 0, 2, dev, 5).float()
         out = torch.empty((M, Nout), dtype=F32, device=dev)
-        ops.gemm(a, K, 0, w, K, 0, M, Nout, K, kind=L.EPI_RESIDUAL_F32, out=out, ldc=Nout, res=res, rowscale=rs,
+        ops.gemm(a, K, 0, w, Nout if bkm else K, bkm, M, Nout, K, kind=L.EPI_RESIDUAL_F32, out=out, ldc=Nout, res=res, rowscale=rs,
                  rows_per_scale=N)
         assert torch.equal(out, res + rs.repeat_interleave(N)[:, None] * ref)
 

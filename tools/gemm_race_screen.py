@@ -8,7 +8,9 @@ from devit_amd import ops, _lib as L
 dev = torch.device("cuda"); BF = torch.bfloat16
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 cases = [(50688, 1152, 384, 0, 0), (50688, 2304, 768, 0, 0), (50688, 768, 3072, 2, 0), (50688, 1536, 384, 1, 0),
-         (50688, 384, 1536, 0, 1), (50688, 1536, 384, 4, 1), (12800, 2304, 768, 0, 0), (9088, 384, 1536, 6, 0)]
+         (50688, 384, 1536, 0, 1), (50688, 1536, 384, 4, 1), (12800, 2304, 768, 0, 0), (9088, 384, 1536, 6, 0),
+         # the full-row 256x384 kernel: fc2's forward through a k-major weight (fp32 residual), qkv's / proj's dgrads, two tiles per workgroup
+         (50688, 384, 1536, 2, 1), (50688, 384, 1152, 0, 1), (76800, 384, 384, 0, 1)]
 bad = 0
 for M, N, K, kind, bkm in cases:
     worst = 0.0

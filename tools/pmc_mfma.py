@@ -33,7 +33,8 @@ def main():
     # the bench's dominant template: every gemm_kernel<.., A_KM=false, B_KM=false, ..> instantiation and the four-wave kernel
     # (gemm4_kernel<KIND, F16>: row-major x row-major by construction)
     dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+(, (true|false))?>", k)
-           or re.search(r"gemm4_kernel<\d+, (true|false)>", k)]
+           or re.search(r"gemm4_kernel<\d+, (true|false)>", k)
+           or "gemmfr_kernel<2>" in k]       # (+ the full-row kernel with the residual epilogue: the student's fc2 forward)
     assert dom, "no gemm_kernel<.., A_KM=false, B_KM=false, ..> dispatch found: the kernel-name pattern is stale"
     busy = sum(tot[k]["SQ_VALU_MFMA_BUSY_CYCLES"] for k in dom)
     act = sum(tot[k]["GRBM_GUI_ACTIVE"] for k in dom) / 8.0 * 1024.0

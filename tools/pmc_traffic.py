@@ -35,7 +35,8 @@ def main():
     # the bench's dominant template: every gemm_kernel<.., A_KM=false, B_KM=false, ..> instantiation and the four-wave kernel
     # (gemm4_kernel<KIND, F16>: row-major x row-major by construction)
     dom = [k for k in rows if re.search(r"gemm_kernel<\d+, \d+, \d+, \d+, \d+, false, false, \d+(, (true|false))?>", k)
-           or re.search(r"gemm4_kernel<\d+, (true|false)>", k)]
+           or re.search(r"gemm4_kernel<\d+, (true|false)>", k)
+           or "gemmfr_kernel<2>" in k]       # (+ the full-row kernel with the residual epilogue: the student's fc2 forward)
     assert dom, "no gemm_kernel<.., A_KM=false, B_KM=false, ..> dispatch found: the kernel-name pattern is stale"
     n = sum(rows[k]["launches"] for k in dom)
     fetch = sum(rows[k]["fetch_bytes_per_launch"] * rows[k]["launches"] for k in dom) / max(n, 1)
