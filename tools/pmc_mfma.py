@@ -43,7 +43,7 @@ def main():
     res = {"kernel_sources_hash": bench.kernel_sources_hash(), "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
                      "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace over bench.py --steps 2 --warmup 1 "
                      "--teacher-lookahead 0 (one launch at a time)",
-           "dominant_template": "gemm_kernel<*, A_row, B_row, *> + gemm4_kernel<*>", "mfma_busy": round(busy / max(act, 1.0), 4),
+           "dominant_template": "gemm_kernel<*, A_row, B_row, *> + gemm4_kernel<*> + gemmfr_kernel<2> (the student's fc2 forward)", "mfma_busy": round(busy / max(act, 1.0), 4),
            "kernels": {k[:120]: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                        for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["gui_active_cycles_per_launch"] * kv[1]["launches"])[:24]}}
     json.dump(res, open(out, "w"), indent=1)

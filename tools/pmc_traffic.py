@@ -45,7 +45,7 @@ def main():
     import bench                   # kernel_sources_hash(): which kernel sources this summary was taken on
     res = {"kernel_sources_hash": bench.kernel_sources_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 "
                      "--teacher-lookahead 0; FETCH_SIZE x2 (gfx950 128-B requests counted as 64 B); Infinity-Cache hits included",
-           "dominant_template": "gemm_kernel<*, A_row, B_row, *> + gemm4_kernel<*>", "launches": n,
+           "dominant_template": "gemm_kernel<*, A_row, B_row, *> + gemm4_kernel<*> + gemmfr_kernel<2> (the student's fc2 forward)", "launches": n,
            "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
            "traffic_bytes_per_launch": round(fetch + write),
            "kernels": {k[:120]: {kk: (round(vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
