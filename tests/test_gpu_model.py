@@ -4,8 +4,10 @@ own modules (tests/golden/*.npz) and (b) the CPU oracle on fresh seeded inputs.
 Tolerances.  The HIP path computes in bf16 (MFMA operands and stored branch activations; fp32 accumulate,
 fp32 residual stream, fp32 LN / softmax / loss statistics).  The reference's own modules run under
 torch.autocast(bfloat16) differ from their fp32 run by 1.2e-2 of max|logit| (tests/golden/model_*_bf16.npz,
-SURVEY fact 8).  The bf16-mode bars are set at about twice what the kernels measure on MI355X (profiles/*parity*):
-logits within 1.5e-2 of max|logit| (measured 7.5e-3), top-1 indices bit-exact on the fixture set, the step's losses within
+SURVEY fact 8).  The bf16-mode bars are set from what the kernels measure on MI355X (profiles/*parity*): logits within 1.5e-2 of
+max|logit| -- 1.9x the golden batch's 8.0e-3 / 7.6e-3 but only 1.6x the worst of seven other seeded batches (9.6e-3 for DeiT-B,
+profiles/r04_e_parity_spread.json: the statistic is a maximum over 200 logits of bf16 rounding noise and moves from batch to batch) and
+1.25x the reference's own bf16-autocast deviation --, top-1 indices bit-exact on the fixture set, the step's losses within
 5e-4 relative (8e-5), gradient norms within 3e-3 (6e-4), gradient slices within 1e-2 of their max (3.8e-3); every check goes
 through conftest.chk, which records value and bar (gpurun_out/parity_margins.json).  BASELINE.json's 1e-3 bar is asserted
 on the exact-fp32 path (`precision="f32"`, test_f32_path_meets_1e3_bar; measured 2e-6)."""
@@ -60,7 +62,7 @@ def test_model_forward_vs_golden(golden, models, dev, which):
         d = m(img, distill_token=True, output_qkv=True, output_att=True, output_emb=True, output_encoders=True)
     assert isinstance(logits, torch.Tensor) and logits.shape == (8, C)
     e = rel(logits, g["logits"])
-    assert chk(e, 1.5e-2), f"logits rel-to-max err {e:.3e}"        # measured 7.5e-3 / 5.8e-3 (profiles/r01_parity_report.json)
+    assert chk(e, 1.5e-2), f"logits rel-to-max err {e:.3e}"        # measured 8.0e-3 / 7.6e-3 (profiles/r05_H_parity_margins.json; 9.6e-3 at worst over seven batches)
     assert np.array_equal(logits.argmax(1).cpu().numpy(), g["top1"])            # top-1 bit-exact
     assert set(d) == {"output", "qkv", "attention", "encoder", "last_tokens"}
     assert len(d["qkv"]) == 12 and len(d["attention"]) == 12 and len(d["encoder"]) == 13
