@@ -8,6 +8,9 @@
 // k-contiguous operands (ds_read_b128 fragments), swz_krow() for k-major operands (ds_read_b64_tr_b16 fragments).
 // Epilogues run straight from the accumulators (epilogue_direct): the MFMAs take the weight operand on their row
 // side so each lane owns consecutive output columns; only the split-K atomic epilogue stages through LDS.
+// Three kernels share the images, swizzles, epilogue code and accumulation order (bit-identical results wherever two of them can run a launch):
+// gemm_kernel (eight waves, 128x128 / 256x256 ping-pong), gemm4_kernel (four waves, 256x256, generated asm K loop: gemm4_kloop.inc) and
+// gemmfr_kernel (four waves, full-row 256x384 for N = 384 outputs with a k-major weight, generated asm K loop: gemmfr_kloop.inc).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -1249,6 +1252,10 @@ void gemmfr_kernel(const GemmArgs g) {
           for (int jp = 0; jp < 2; ++jp) dsB[2 * x3 + jp] = row + (unsigned)(32 * (jp ^ (gq & 1)) + 16 * (p >> 1) + 8 * (p & 1));
         }
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dsA[i] += lds_base;      // (the asm adds only the slot offsets: the ring need not start at LDS address 0)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dsB[i] += lds_base;
 #pragma unroll
       for (int i = 0; i < 4; ++i) dmaA[i] = lane_offset<false, BM, NWAVES>(g.lda, wave, lane_k, i, BM);
 #pragma unroll
