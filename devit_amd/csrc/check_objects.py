@@ -24,6 +24,28 @@ def run(*cmd):
     return p.stdout
 
 
+def scan_agpr_writes(disassembly):
+    """(violations, MFMAs seen) over `llvm-objdump -d` text: inside the asm-accumulator kernels every instruction whose destination is an
+    a-register must be an MFMA (tests/test_abi.py feeds it synthetic text)."""
+    bad, cur, seen = [], None, 0
+    for line in disassembly.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            if not m.group(1).startswith("L_"):          # (labels of the asm statements stay inside their kernel)
+                cur = m.group(1)
+            continue
+        if cur is None or not any(k in cur for k in ASM_ACC_KERNELS):
+            continue
+        m = re.match(r"^\s+(\S+)\s+([^,\s]+)", line)
+        if not m:
+            continue
+        op, dst = m.group(1), m.group(2)
+        if op.startswith("v_accvgpr_write") or (re.match(r"^a(\d+|\[)", dst) and not op.startswith("v_mfma")):
+            bad.append(f"{cur}: `{line.strip()[:90]}` writes an AGPR outside an MFMA")
+        seen += op.startswith("v_mfma")
+    return bad, seen
+
+
 def main(build, names):
     for tool in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf", "llvm-objdump"):
         if not os.access(os.path.join(LLVM, tool), os.X_OK):
@@ -53,23 +75,8 @@ def main(build, names):
                 if m and int(m.group(1)) > 0:
                     bad.append(f"{f}.hip: {name} uses {m.group(1)} B of scratch")
             if any(any(k in n for k in ASM_ACC_KERNELS) for n in kernels):
-                dis = run(os.path.join(LLVM, "llvm-objdump"), "-d", co)
-                cur, seen = None, 0
-                for line in dis.splitlines():
-                    m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
-                    if m:
-                        if not m.group(1).startswith("L_"):          # (labels of the asm statements stay inside their kernel)
-                            cur = m.group(1)
-                        continue
-                    if cur is None or not any(k in cur for k in ASM_ACC_KERNELS):
-                        continue
-                    m = re.match(r"^\s+(\S+)\s+([^,\s]+)", line)
-                    if not m:
-                        continue
-                    op, dst = m.group(1), m.group(2)
-                    if op.startswith("v_accvgpr_write") or (re.match(r"^a(\d+|\[)", dst) and not op.startswith("v_mfma")):
-                        bad.append(f"{f}.hip: {cur}: `{line.strip()[:90]}` writes an AGPR outside an MFMA")
-                    seen += op.startswith("v_mfma")
+                found, seen = scan_agpr_writes(run(os.path.join(LLVM, "llvm-objdump"), "-d", co))
+                bad += [f"{f}.hip: {x}" for x in found]
                 if seen == 0:
                     sys.exit(f"check_objects: {f}.o: the disassembly of the asm-accumulator kernels shows no MFMA: the gate is not seeing them")
         finally:

@@ -170,3 +170,31 @@ def test_full_row_rule_is_mirrored(monkeypatch):
     assert not ops.full_row_selected(50688, 384, 1536)
     monkeypatch.setenv("DEVIT_GEMMFR", "1")
     assert ops.full_row_selected(512, 384, 1536)
+
+
+def test_build_gate_sees_agpr_writes():
+    """csrc/check_objects.py (run by build.sh): in the kernels whose asm K loops leave their accumulators in literal AGPRs, any instruction other than an
+    MFMA that writes an a-register fails the build -- checked here on synthetic `llvm-objdump -d` text (the real objects pass: build() ran the gate)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_objects", os.path.join(ROOT, "devit_amd", "csrc", "check_objects.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ok = """
+0000000000001000 <_ZN12_GLOBAL__N_112gemm4_kernelILi0ELb0EEEvNS_8GemmArgsE>:
+\tv_mfma_f32_16x16x32_bf16 a[0:3], v[160:163], v[128:131], a[0:3] // 000000001000: D3B58000
+\tv_accvgpr_read_b32 v5, a17                                 // 000000001008: D3D84005
+\tds_read_b128 v[128:131], v9                                // 000000001010: D9FE0000
+0000000000001100 <L_gemm4_w1_7>:
+\tv_mfma_f32_16x16x32_bf16 a[4:7], v[164:167], v[128:131], a[4:7] // 000000001100: D3B58004
+0000000000002000 <_ZN12_GLOBAL__N_111some_kernelEv>:
+\tv_accvgpr_write_b32 a3, v1                                 // 000000002000: D3D94003
+"""
+    bad, seen = mod.scan_agpr_writes(ok)
+    assert bad == [] and seen == 2            # (the write in some_kernel is not our business)
+    for line in ("\tv_accvgpr_write_b32 a7, v3                                 // 0000: D3D94007",
+                 "\tglobal_load_dword a12, v[2:3], off                         // 0000: DC508000",
+                 "\tds_read_b128 a[8:11], v9                                   // 0000: D9FE0000"):
+        bad, _ = mod.scan_agpr_writes(ok.replace("0000000000001100 <L_gemm4_w1_7>:", line + "\n0000000000001100 <L_gemm4_w1_7>:"))
+        assert len(bad) == 1 and "gemm4_kernel" in bad[0], line
+    bad, _ = mod.scan_agpr_writes(ok.replace("gemm4_kernelILi0ELb0EEE", "gemmfr_kernelILi2EEE").replace("\tv_accvgpr_read_b32 v5, a17", "\tv_accvgpr_write_b32 a17, v5"))
+    assert len(bad) == 1 and "gemmfr_kernel" in bad[0]
