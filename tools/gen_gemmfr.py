@@ -184,12 +184,27 @@ def phase(e, wave, zero, reads, reqs, vmcnt, units_head, units_tail):
                 for s in units_head[n]:
                     e(s)
             if n == BAR_GAP:
+                vm_split = STAMP and os.environ.get("GEMMFR_STAMP_VM") == "1"   # experiment: d2 = the vmcnt wait alone, d1 = the barrier alone
                 if STAMP:
                     e(f"s_memtime s[{ST['t1']}:{ST['t1'] + 1}]")
+                if vm_split:
+                    e("s_waitcnt lgkmcnt(0)")
+                    e(f"s_mov_b32 s{ST['t0']}, s{ST['t1']}")
                 e(f"s_waitcnt vmcnt({0 if NOREQ else vmcnt})")
                 e("s_waitcnt lgkmcnt(0)")
+                if vm_split:
+                    e(f"s_memtime s[{ST['t1']}:{ST['t1'] + 1}]")
+                    e("s_waitcnt lgkmcnt(0)")
+                    e(f"s_sub_u32 s{ST['t0'] + 1}, s{ST['t1']}, s{ST['t0']}")
+                    e(f"s_add_u32 s{ST['d2']}, s{ST['d2']}, s{ST['t0'] + 1}")
+                    e(f"s_mov_b32 s{ST['t0']}, s{ST['t1']}")
                 e("s_barrier")
-                if STAMP:   # d1 += phase (stamp to stamp), d2 += barrier wait
+                if vm_split:
+                    e(f"s_memtime s[{ST['t1']}:{ST['t1'] + 1}]")
+                    e("s_waitcnt lgkmcnt(0)")
+                    e(f"s_sub_u32 s{ST['t0'] + 1}, s{ST['t1']}, s{ST['t0']}")
+                    e(f"s_add_u32 s{ST['d1']}, s{ST['d1']}, s{ST['t0'] + 1}")
+                elif STAMP:   # d1 += phase (stamp to stamp), d2 += barrier wait
                     e(f"s_sub_u32 s{ST['t0'] + 1}, s{ST['t1']}, s{ST['t0']}")
                     e(f"s_add_u32 s{ST['d1']}, s{ST['d1']}, s{ST['t0'] + 1}")
                     e(f"s_mov_b32 s{ST['t0']}, s{ST['t1']}")
