@@ -482,7 +482,7 @@ def main():
                 "student_frac": round(B * (GFLOP_PER_IMG_STEP - 35.311) * 1e9 / (student_ms * 1e-3) / BF16_DENSE_PEAK, 4),
                 "counts": "ALGORITHMIC FLOPs (teacher forward 35.311, student forward + backward + relation losses 28.192 GFLOP per image) / "
                           "event time of the serialized step's halves / 2.5 PFLOP/s"}
-    ops.PROFILE, ops.PROFILE_HBM = [], []
+    ops.PROFILE, ops.PROFILE_HBM, ops.PROFILE_WGRAD = [], [], []
     opt_events = []
     step()
     torch.cuda.synchronize()
@@ -490,6 +490,7 @@ def main():
     opt_events = None
     recs, ops.PROFILE = ops.PROFILE, None
     hbm_recs, ops.PROFILE_HBM = ops.PROFILE_HBM, None
+    wg_recs, ops.PROFILE_WGRAD = ops.PROFILE_WGRAD, None
     # the bandwidth-bound kernels of the same serialized step: algorithmic bytes / event time (HBM peak 8 TB/s)
     hbm = {}
     for name, nbytes, e0, e1 in hbm_recs:
@@ -505,6 +506,13 @@ def main():
         d[0] += 2.0 * M * N * K * batch
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
+    # the grouped weight-gradient launches (devit_wgrad_grouped: a block's four products in one launch of the full-row k-major x k-major kernel)
+    if wg_recs:
+        wt = sum(e0.elapsed_time(e1) * 1e-3 for _, _, e0, e1 in wg_recs)
+        by_t["A_km/B_km grouped (wgradfr_kernel)"] = [sum(f for f, _, _, _ in wg_recs), wt, len(wg_recs)]
+        hbm["wgrad_grouped"] = {"GB/s": round(sum(b for _, b, _, _ in wg_recs) / wt / 1e9, 1),
+                                "frac_of_8TB/s": round(sum(b for _, b, _, _ in wg_recs) / wt / 8e12, 3), "launches": len(wg_recs),
+                                "ms_per_step": round(wt * 1e3, 3)}
     dom = "A_row/B_row"
     fl, tm, cnt = by_t[dom]
     traffic, traffic_src = committed_counter("*_pmc_traffic.json", "traffic_bytes_per_launch")

@@ -52,12 +52,24 @@ class BlockActs(C.Structure):
 class BlockBwdIO(C.Structure):
     _fields_ = [("dx", C.c_void_p), ("g2", C.c_void_p), ("dx_in", C.c_void_p), ("g_prev", C.c_void_p),
                 ("prev_dp2", C.c_void_p), ("prev_fc2_b_grad", C.c_void_p), ("g2_bias_done", C.c_int),
-                ("dqkv_add", C.c_void_p), ("ws", C.c_void_p * 8), ("lnws_bytes", C.c_size_t)]
+                ("dqkv_add", C.c_void_p), ("ws", C.c_void_p * 8), ("lnws_bytes", C.c_size_t),
+                ("defer_jobs", C.c_void_p), ("defer_count", C.c_void_p)]
 
 
 class IndexJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("idx", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
                 ("src_ld", C.c_int), ("dst_ld", C.c_int), ("mode", C.c_int), ("elem", C.c_int)]
+
+
+class WgradJob(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("lda", C.c_int), ("a_cols", C.c_int), ("b", C.c_void_p), ("ldb", C.c_int), ("out", C.c_void_p),
+                ("ldc", C.c_int), ("transposed", C.c_int), ("a_colsum", C.c_void_p)]
+
+
+WGRAD_MAX_JOBS = 48
+ABI_VERSION = 2
+# devit_abi_struct_size(which) -> the mirror it must equal (checked at load time: an array of stale mirrors is misread silently)
+ABI_STRUCTS = {0: Epilogue, 1: Operand, 2: BlockWeights, 3: BlockWgrads, 4: BlockActs, 5: BlockBwdIO, 6: IndexJob, 7: WgradJob}
 
 
 class DevitError(RuntimeError):
@@ -71,6 +83,9 @@ SIGNATURES = {
     "devit_version": (_I, []),
     "devit_last_error": (C.c_char_p, []),
     "devit_check_device": (_I, [_I]),
+    "devit_abi_struct_size": (_Z, [_I]),
+    "devit_gemm_full_row_selected": (_I, [_I, _I, _I, _I]),
+    "devit_wgrad_grouped": (_I, [C.POINTER(WgradJob), _I, _I, _I, _P]),
     "devit_gemm_bf16": (_I, [C.POINTER(Operand), C.POINTER(Operand), _I, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
     "devit_set_reserved_cus": (_I, [_I]),
     "devit_get_reserved_cus": (_I, []),
@@ -133,8 +148,12 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.devit_version() != 1:
-            raise DevitError("libdevit_hip.so ABI version mismatch")
+        if lib.devit_version() != ABI_VERSION:
+            raise DevitError(f"libdevit_hip.so ABI version {lib.devit_version()} != {ABI_VERSION} of this binding: rebuild (devit_amd/csrc/build.sh)")
+        for which, cls in ABI_STRUCTS.items():
+            if lib.devit_abi_struct_size(which) != C.sizeof(cls):
+                raise DevitError(f"libdevit_hip.so: sizeof struct {which} = {lib.devit_abi_struct_size(which)}, the binding's {cls.__name__} has "
+                                 f"{C.sizeof(cls)} bytes: header and binding disagree")
         _lib = lib
     return _lib
 

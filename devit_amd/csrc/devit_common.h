@@ -34,9 +34,6 @@ void devit_set_error(const char* fmt, ...);
     }                                                                   \
   } while (0)
 
-// gemm.hip: would devit_gemm_bf16 run (row-major A) x (K-MAJOR B) with this epilogue kind on the full-row 256x384 kernel?  (the fp32
-// residual epilogue with a k-major weight exists on that kernel only: callers that hold a k-major weight copy ask first)
-bool devit_gemm_full_row_selected(int M, int N, int K, int kind);
 
 // ---- scalar helpers ---------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }

@@ -63,6 +63,29 @@ int linear_wgrad(const Ctx& c, const void* dy, const void* x, float* w_grad, flo
   return devit_gemm_bf16(&A, &Bo, Nw, K, c.Mp, 1, split_k_for(Nw, K, c.Mp / 64), &ep, c.stream);
 }
 
+// The block's weight gradients as jobs of ONE devit_wgrad_grouped launch (the full-row weight-gradient kernel, gemm.hip): possible when
+// one side of every product is exactly 384 features wide (D == 384: the student) and the other a multiple of 128.
+//   dW[Nw][K] += dy^T x:   K == 384 -> tiles over dy's features (column sums of dy = the bias gradient from the same launch);
+//                          Nw == 384 -> the product transposed, tiles over x's features (no bias gradient: the caller has it from elsewhere)
+bool wgrad_job(devit_wgrad_job* j, const void* dy, const void* x, float* w_grad, float* b_grad, int Nw, int K) {
+  if (K == 384 && Nw % 128 == 0) {
+    *j = devit_wgrad_job{dy, Nw, Nw, x, K, w_grad, K, 0, b_grad};
+    return true;
+  }
+  if (Nw == 384 && K % 128 == 0 && b_grad == nullptr) {
+    *j = devit_wgrad_job{x, K, K, dy, Nw, w_grad, K, 1, nullptr};
+    return true;
+  }
+  return false;
+}
+// DEVIT_WGRADFR (read per call: tests switch it): 0 = four split-K launches on 128x128 tiles (rounds 1-5); else (default) the grouped launch
+// (two launches per block -- the MLP pair behind the fc1 dgrad, the attention pair behind the qkv dgrad, for the Infinity Cache -- measured
+// 4 % slower on the step than one: twice the atomics)
+int wgrad_mode() {
+  const char* e = getenv("DEVIT_WGRADFR");
+  return (e && *e) ? atoi(e) != 0 : 1;
+}
+
 #define TRY(x)                 \
   do {                         \
     int rc__ = (x);            \
@@ -275,8 +298,34 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
   TRY(zero_pad(c, io->g_prev, D, 2));
   // ---- MLP branch: x2 = x1 + dp2 * fc2(gate * gelu(fc1(ln2))).  The weight gradient that only needs g2 first, then
   // dh_pre's producer and its consumers back to back (dh_pre is 156 MB at B = 256: keep it in the Infinity Cache)
-  TRY(fork(0));
-  TRY(linear_wgrad(cs, io->g2, b[DEVIT_ACT_H], g.fc2_w, io->g2_bias_done ? nullptr : g.fc2_b, D, Hd));
+  // Weight gradients: jobs of the grouped full-row launch where the shapes allow (D == 384), else -- and for a product whose bias gradient
+  // must come from its B side (the top block's fc2) -- the split-K launch on 128x128 tiles, behind the kernel that produces its operand.
+  const int wmode = (D == 384 && c.Mp / 64 >= 3) ? wgrad_mode() : 0;
+  if (io->defer_count) *io->defer_count = 0;
+  devit_wgrad_job jobs[4];
+  int nj = 0;
+  auto wgrad = [&](int ev, const void* dy, const void* x, float* w_grad, float* b_grad, int Nw, int K) -> int {
+    if (wmode && wgrad_job(&jobs[nj], dy, x, w_grad, b_grad, Nw, K)) {
+      ++nj;
+      return DEVIT_OK;
+    }
+    TRY(fork(ev));
+    return linear_wgrad(cs, dy, x, w_grad, b_grad, Nw, K);
+  };
+  auto flush = [&](int ev) -> int {
+    if (io->defer_jobs) {           // the caller launches them later, with other blocks' (devit_block_bwd_io.defer_jobs)
+      for (int i = 0; i < nj; ++i) io->defer_jobs[i] = jobs[i];
+      if (io->defer_count) *io->defer_count = nj;
+      nj = 0;
+      return DEVIT_OK;
+    }
+    if (nj == 0) return DEVIT_OK;
+    TRY(fork(ev));
+    const int n = nj;
+    nj = 0;
+    return devit_wgrad_grouped(jobs, n, c.Mp, 0, cs.stream);
+  };
+  TRY(wgrad(0, io->g2, b[DEVIT_ACT_H], g.fc2_w, io->g2_bias_done ? nullptr : g.fc2_b, D, Hd));
   {
     devit_epilogue ep = make_ep(DEVIT_EPI_DGELU_BF16, dh_pre, Hd, c.M);
     ep.colscale = w.neuron_gate;
@@ -284,21 +333,19 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
     TRY(linear_dgrad(c, io->g2, w.fc2_w16, D, Hd, ep));
   }
   TRY(linear_dgrad(c, dh_pre, w.fc1_w16, Hd, D, make_ep(DEVIT_EPI_STORE_BF16, dln2, D, c.M)));
-  TRY(fork(1));
-  TRY(linear_wgrad(cs, dh_pre, b[DEVIT_ACT_LN2], g.fc1_w, g.fc1_b, Hd, D));
+  TRY(wgrad(1, dh_pre, b[DEVIT_ACT_LN2], g.fc1_w, g.fc1_b, Hd, D));
   // LN2 backward: dx1 = dx + LN'(dln2); g1 = bf16(dp1 * dx1); its column sums = the proj bias gradient
   TRY(devit_layernorm_bwd(dln2, 0, (const float*)b[DEVIT_ACT_X1], c.M, D, 0, 0, (const float*)b[DEVIT_ACT_MEAN2],
                           (const float*)b[DEVIT_ACT_RSTD2], w.n2w, io->dx, dx1, g1, a.dp1, N, g.n2w, g.n2b, g.proj_b, 1,
                           io->ws[DEVIT_BWD_LNWS], io->lnws_bytes, stream));
   // ---- attention branch: x1 = x + dp1 * proj(gate * attn(qkv(ln1)))
   TRY(linear_dgrad(c, g1, w.proj_w16, D, Da, make_ep(DEVIT_EPI_STORE_BF16, dattn, Da, c.M)));
-  TRY(fork(2));
-  TRY(linear_wgrad(cs, g1, b[DEVIT_ACT_ATTN_O], g.proj_w, nullptr, D, Da));
+  TRY(wgrad(2, g1, b[DEVIT_ACT_ATTN_O], g.proj_w, nullptr, D, Da));
   TRY(devit_attn_bwd(b[DEVIT_ACT_QKV], b[DEVIT_ACT_ATTN_O], dattn, (const float*)b[DEVIT_ACT_LSE], w.head_gate, io->dqkv_add,
                      dqkv, B, N, H, 64, 0.125f, stream));
   TRY(linear_dgrad(c, dqkv, w.qkv_w16, 3 * Da, D, make_ep(DEVIT_EPI_STORE_BF16, dln1, D, c.M)));
-  TRY(fork(3));
-  TRY(linear_wgrad(cs, dqkv, b[DEVIT_ACT_LN1], g.qkv_w, g.qkv_b, 3 * Da, D));
+  TRY(wgrad(3, dqkv, b[DEVIT_ACT_LN1], g.qkv_w, g.qkv_b, 3 * Da, D));
+  TRY(flush(3));
   // LN1 backward: dx_in = dx1 + LN'(dln1); g_prev = bf16(prev_dp2 * dx_in) (+ the block below's fc2 bias gradient)
   TRY(devit_layernorm_bwd(dln1, 0, a.x, c.M, D, 0, 0, (const float*)b[DEVIT_ACT_MEAN1], (const float*)b[DEVIT_ACT_RSTD1],
                           w.n1w, dx1, io->dx_in, io->g_prev, io->prev_dp2, N, g.n1w, g.n1b,

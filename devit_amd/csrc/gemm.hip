@@ -1365,6 +1365,229 @@ void gemmfr_kernel(const GemmArgs g) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradients on the full-row tile (round 6): out (+)= A^T B over the token rows, BOTH operands k-major ([K][features], as the step holds
+// dY and X), a table of up to eight jobs = the Linear layers of one block (or of several) in ONE launch, one 256 x 384 tile and one K slice per
+// workgroup, all of them resident at once.  Why: the split-K 128x128 launches this replaces (four per block) asked the CU's fill path for
+// 64 B per cycle of matrix pipe where it delivers ~24 and ran 14-56-step K loops in front of 64 KB of atomics each;
+// this tile needs 26.7 B per cycle, reads the dY panel once, and a block's four products are 19 tiles x 13 slices = 247 workgroups with
+// ~61-step K loops.  K loop: the generated asm statement DEVIT_WGRADFR_KLOOP (tools/gen_gemmfr.py, KMA variant: the ring protocol, phases and
+// waits of gemmfr_kernel; A image [64 k][256], fragments by ds_read_b64_tr_b16 on both sides, PAIRED tile-row order on both sides, column
+// sums of A by v_dot2c against packed ones).  Epilogue: the accumulators go through LDS 32 rows at a time and leave as fp32 atomics on whole
+// 256-byte rows (128-byte columns for a transposed job).
+constexpr int WGRAD_MAX_JOBS = 48;
+struct WgJob {
+  const __bf16* a;
+  const __bf16* b;
+  float* out;
+  float* colsum;
+  int lda, ldb, ldc, a_cols, transposed, tile0;    // tile0: index of the job's first tile in the table's tile list
+};
+struct WgArgs {
+  WgJob job[WGRAD_MAX_JOBS];
+  int njobs, tiles, split, nk_total, total;
+  unsigned long long* dbg;       // stamped diagnostic build only (tools/wgradfr_stamps.py)
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void wgradfr_kernel(const WgArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 384, NWAVES = 4;
+  constexpr int A_SLOT = BM * BK * 2, B_SLOT = BN * BK * 2, B_RING = 2 * A_SLOT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // workgroups b, b + 8, ... share an XCD: each XCD takes a contiguous run of (slice, tile) pairs, tile fastest -- the tiles of one job and
+  // slice (2-6 of them) read the same B rows at the same time through that XCD's L2
+  int L;
+  {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = g.total >> 3, r = g.total & 7;
+    if (idx >= q + (xcd < r ? 1 : 0)) return;
+    L = xcd * q + min(xcd, r) + idx;
+  }
+#ifdef DEVIT_GEMMFR_STAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+  const int z = L / g.tiles, t = L - z * g.tiles;
+  int ji = 0;
+  for (int j = 1; j < g.njobs; ++j)
+    if (t >= g.job[j].tile0) ji = j;
+  const WgJob& jb = g.job[ji];
+  const int m0 = (t - jb.tile0) * BM;
+  const int valid = min(BM, jb.a_cols - m0);                    // 256 or 128 columns of A exist in this tile
+  const int kt0 = (int)((long long)z * g.nk_total / g.split);
+  const int nk_i = (int)((long long)(z + 1) * g.nk_total / g.split) - kt0;
+  const int lda = jb.lda, ldb = jb.ldb;
+  const __bf16* a_tile = jb.a + (size_t)kt0 * BK * lda + m0;    // &A[k0][m0]
+  const __bf16* b_sl = jb.b + (size_t)kt0 * BK * ldb;           // &B[k0][0]
+  const int Ks = nk_i * BK;                                     // the slice: B's half-stage-shifted stream is cyclic in it
+
+  const unsigned ldas = (unsigned)lda * 128u, ldbs = (unsigned)ldb * 128u, kb = (unsigned)Ks * (unsigned)ldb * 2u;
+  const unsigned lds_base = (unsigned)(size_t)LDS_PTR(smem);
+  const unsigned wldsa = lds_base + (unsigned)wave * 8192u, wldsb = lds_base + (unsigned)wave * 12288u;
+
+  // prologue: stages 0, 1 of both operands
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    stage_tile<true, BM, NWAVES, true>(a_tile, lda, st * BK, 0, 0, smem + st * A_SLOT, wave, lane, valid);
+    const char* ub = (const char*)(b_sl + (size_t)fr_b_row(st, wave, Ks) * ldb);
+    const unsigned lds0 = lds_base + (unsigned)(B_RING + st * B_SLOT) + (unsigned)wave * 12288u;
+#pragma unroll
+    for (int i = 0; i < 12; i += 2)
+      dma2_uniform<false>(ub, fr_dma_off_b(ldb, wave, lane, i), fr_dma_off_b(ldb, wave, lane, i + 1), lds0 + i * 1024u);
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#ifdef DEVIT_GEMMFR_STAMP
+  const unsigned long long t_primed = __builtin_amdgcn_s_memtime();
+#endif
+  unsigned acur = 0;
+  const unsigned wv = (unsigned)wave, nk = (unsigned)nk_i;
+  const unsigned bv2 = (unsigned)fr_b_row(2, wave, Ks) * (unsigned)ldb * 2u;
+  const unsigned bplo = (unsigned)(uintptr_t)b_sl, bphi = (unsigned)((uintptr_t)b_sl >> 32);
+  const unsigned ones = jb.colsum ? 0x3f803f80u : 0u;
+
+  // per-lane constants of the K loop (gen_gemmfr.py, KMA variant)
+  unsigned dsA[4], dsB[4], dmaA[8], dmaB[12];
+  {
+    int lane_k;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_k));
+    const int gq = lane_k >> 4, q4 = (lane_k >> 2) & 3, p = lane_k & 3;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      dsA[x] = lds_base + (unsigned)((gq * 8 + q4) * (BM * 2) + 256 * wm + 64 * (x ^ q4) + 16 * (p ^ ((gq & 1) << 1)));
+      dsB[x] = lds_base + (unsigned)((gq * 8 + q4) * (BN * 2) + 64 * (x ^ q4) + 16 * (p ^ ((gq & 1) << 1)));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dmaA[i] = lane_offset<true, BM, NWAVES>(lda, wave, lane_k, i, valid);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dmaB[i] = fr_dma_off_b(ldb, wave, lane_k, i);
+  }
+  unsigned t0, t1, t2, t3, t4, t5, t6, t7;
+  float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;
+  f32x32 c0, c1, c2, c3;
+#ifdef DEVIT_GEMMFR_STAMP
+  unsigned d1, d2;
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#define DEVIT_WG_STAMP_OUT , [d1] "=&s"(d1), [d2] "=&s"(d2)
+#define DEVIT_WG_ASM DEVIT_WGRADFR_KLOOP_STAMPED_ASM
+#define DEVIT_WG_CLOB DEVIT_WGRADFR_KLOOP_STAMPED_CLOBBERS
+#else
+#define DEVIT_WG_STAMP_OUT
+#define DEVIT_WG_ASM DEVIT_WGRADFR_KLOOP_ASM
+#define DEVIT_WG_CLOB DEVIT_WGRADFR_KLOOP_CLOBBERS
+#endif
+  asm volatile(DEVIT_WG_ASM
+               : [c0] "=&{v[128:159]}"(c0), [c1] "=&{v[160:191]}"(c1), [c2] "=&{v[192:223]}"(c2), [c3] "=&{v[224:255]}"(c3),
+                 [acur] "+s"(acur), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4),
+                 [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [rs0] "+v"(rs0), [rs1] "+v"(rs1), [rs2] "+v"(rs2), [rs3] "+v"(rs3) DEVIT_WG_STAMP_OUT
+               : [aptr] "s"(a_tile), [bplo] "s"(bplo), [bphi] "s"(bphi), [bv2] "s"(bv2), [kb] "s"(kb), [nk] "s"(nk), [ldas] "s"(ldas),
+                 [ldbs] "s"(ldbs), [wldsa] "s"(wldsa), [wldsb] "s"(wldsb), [wv] "s"(wv), [ones] "s"(ones),
+                 [dsa0] "v"(dsA[0]), [dsa1] "v"(dsA[1]), [dsa2] "v"(dsA[2]), [dsa3] "v"(dsA[3]),
+                 [dsb0] "v"(dsB[0]), [dsb1] "v"(dsB[1]), [dsb2] "v"(dsB[2]), [dsb3] "v"(dsB[3]),
+                 [dmaa0] "v"(dmaA[0]), [dmaa1] "v"(dmaA[1]), [dmaa2] "v"(dmaA[2]), [dmaa3] "v"(dmaA[3]),
+                 [dmaa4] "v"(dmaA[4]), [dmaa5] "v"(dmaA[5]), [dmaa6] "v"(dmaA[6]), [dmaa7] "v"(dmaA[7]),
+                 [dmab0] "v"(dmaB[0]), [dmab1] "v"(dmaB[1]), [dmab2] "v"(dmaB[2]), [dmab3] "v"(dmaB[3]),
+                 [dmab4] "v"(dmaB[4]), [dmab5] "v"(dmaB[5]), [dmab6] "v"(dmaB[6]), [dmab7] "v"(dmaB[7]),
+                 [dmab8] "v"(dmaB[8]), [dmab9] "v"(dmaB[9]), [dmab10] "v"(dmaB[10]), [dmab11] "v"(dmaB[11])
+               : DEVIT_WG_CLOB);
+#undef DEVIT_WG_STAMP_OUT
+#undef DEVIT_WG_ASM
+#undef DEVIT_WG_CLOB
+#ifdef DEVIT_GEMMFR_STAMP
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- epilogue.  Lane (g, c) holds, for A tile i and B tile q, register r:  C[row(i, c)][col(q, 4 g + r)] with the PAIRED tile-row order on
+  // both sides: row(i, c) = 32 (i >> 1) + 8 (c >> 2) + 4 (i & 1) + (c & 3) of the wave's 128, col(q, .) = 32 (q >> 1) + 8 g + 4 (q & 1) + r of
+  // its 192.  Pass k stages the A tiles (2 k, 2 k + 1) = rows 32 k .. 32 k + 31 as [32][192 (+4)] floats in the wave's own LDS region
+  // (the ring is free: the K loop's last requests were waited for in its last step) and adds them to `out` a whole row piece per instruction.
+  __syncthreads();             // every wave's last fragment reads are done
+  int lane_e;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+  constexpr int PITCH = 196;
+  float* cw = (float*)smem + wave * (32 * PITCH);
+  const int gq = lane_e >> 4, c = lane_e & 15;
+  const bool wave_valid = wm * 128 < valid;                  // (a half tile: the rows of the wm = 1 waves do not exist)
+  float* wrow = cw + (8 * (c >> 2) + (c & 3)) * PITCH + 8 * gq;
+  auto stage = [&](const f32x4 (&acc)[2][4], int H) {       // n-tiles 4 H .. 4 H + 3 of A tiles (2 k, 2 k + 1)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(wrow + 4 * u * PITCH + 32 * ((4 * H + j) >> 1) + 4 * (j & 1)) = acc[u][j];
+  };
+  auto flush = [&](int k) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int mb = m0 + wm * 128 + 32 * k;                   // first output row (= A column) of the pass
+    if (!jb.transposed) {
+      float* o = jb.out + (size_t)mb * jb.ldc + wn * 192 + lane_e;
+#pragma unroll 4
+      for (int row = 0; row < 32; ++row) {
+        const float* src = cw + row * PITCH + lane_e;
+        const float v0 = src[0], v1 = src[64], v2 = src[128];
+        float* d = o + (size_t)row * jb.ldc;
+        unsafeAtomicAdd(d, v0);
+        unsafeAtomicAdd(d + 64, v1);
+        unsafeAtomicAdd(d + 128, v2);
+      }
+    } else {
+      const int row = lane_e & 31, nsub = lane_e >> 5;
+      float* o = jb.out + (size_t)(wn * 192 + nsub) * jb.ldc + mb + row;
+      const float* src = cw + row * PITCH + nsub;
+#pragma unroll 4
+      for (int n2 = 0; n2 < 96; ++n2) unsafeAtomicAdd(o + (size_t)(2 * n2) * jb.ldc, src[2 * n2]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the region is rewritten by the next pass)
+  };
+  auto from_v = [&](const f32x32& cv) {
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[u][j] = (f32x4){cv[16 * u + 4 * j], cv[16 * u + 4 * j + 1], cv[16 * u + 4 * j + 2], cv[16 * u + 4 * j + 3]};
+    stage(acc, 2);
+  };
+  auto pass = [&](auto kc, const f32x32& cv) {
+    constexpr int k = decltype(kc)::value;
+    if (wave_valid) {
+      from_v(cv);
+      f32x4 acc[2][4];
+      gemmfr_read_acc<0, 2 * k>(acc);
+      stage(acc, 0);
+      gemmfr_read_acc<1, 2 * k>(acc);
+      stage(acc, 1);
+      flush(k);
+    }
+  };
+  pass(std::integral_constant<int, 0>(), c0);
+  pass(std::integral_constant<int, 1>(), c1);
+  pass(std::integral_constant<int, 2>(), c2);
+  pass(std::integral_constant<int, 3>(), c3);
+  if (jb.colsum && wave_valid) {
+    // lane (G, c) holds the sum over ITS k (8 G .. 8 G + 7 of every 32) of tile row c of A tile 2 x + wn: fold the four G
+    float rs[4] = {rs0, rs1, rs2, rs3};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      float v = rs[x];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int i = 2 * x + wn;
+      const int row = wm * 128 + 32 * (i >> 1) + 8 * (c >> 2) + 4 * (i & 1) + (c & 3);
+      if (lane_e < 16) unsafeAtomicAdd(jb.colsum + m0 + row, v);
+    }
+  }
+#ifdef DEVIT_GEMMFR_STAMP
+  if (g.dbg && lane == 0) {      // per wave: K-steps, prologue, K loop, phase sum, barrier-wait sum, epilogue, entry, exit
+    unsigned long long* dbg = g.dbg + ((size_t)blockIdx.x * NWAVES + wave) * 8;
+    const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
+    dbg[0] = nk; dbg[1] = t_primed - t_entry; dbg[2] = ts1 - ts0; dbg[3] = d1; dbg[4] = d2; dbg[5] = t_exit - ts1; dbg[6] = t_entry; dbg[7] = t_exit;
+  }
+#endif
+}
+
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // CUs the persistent grids leave free (devit_set_reserved_cus): -1 = not set yet, take DEVIT_RESERVE_CUS from the environment
@@ -1386,11 +1609,65 @@ int reserved_cus() {
 // profiles/r05_*: the dgrads of qkv / proj / fc1 and fc2's forward; NOT proj's forward (6 K-steps in front of a 57 k-cycle residual epilogue on
 // 198 of 256 CUs: slower than two 128x128 workgroups per CU), which therefore never passes a k-major weight.  DEVIT_GEMMFR=0 / 1 forces it
 // off / on wherever it is built (read per call: tests switch it).
-bool devit_gemm_full_row_selected(int M, int N, int K, int kind) {
+extern "C" int devit_gemm_full_row_selected(int M, int N, int K, int kind) {
   if (!(M > 0 && M % 256 == 0 && N == 384 && K % BK == 0 && K / BK >= 3 && (kind == DEVIT_EPI_RESIDUAL_F32 || kind == DEVIT_EPI_STORE_BF16)))
-    return false;
+    return 0;
   const char* e = getenv("DEVIT_GEMMFR");
-  return e ? atoi(e) != 0 : M / 256 >= 64;    // (a minimum K of 1024 instead of 192 measured the same on the compacted student and 0.5 % less on the dense one)
+  return (e && *e) ? atoi(e) != 0 : M / 256 >= 64;    // (a minimum K of 1024 instead of 192 measured the same on the compacted student and 0.5 % less on the dense one)
+}
+
+#ifdef DEVIT_GEMMFR_STAMP
+static unsigned long long* g_wgrad_dbg = nullptr;
+extern "C" DEVIT_API void devit_wgrad_debug_buffer(void* p) { g_wgrad_dbg = (unsigned long long*)p; }   // [grid x 4 waves x 8] u64, diagnostic build only
+#endif
+
+extern "C" int devit_wgrad_grouped(const devit_wgrad_job* jobs, int njobs, int K, int split_k, void* stream) {
+  DEVIT_CHECK(jobs && njobs >= 1 && njobs <= WGRAD_MAX_JOBS, DEVIT_ERR_ARG, "devit_wgrad_grouped: 1..%d jobs (host array)", WGRAD_MAX_JOBS);
+  DEVIT_CHECK(K > 0 && K % BK == 0, DEVIT_ERR_SHAPE, "devit_wgrad_grouped: K=%d must be a multiple of %d", K, BK);
+  WgArgs g;
+  int tiles = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const devit_wgrad_job& q = jobs[j];
+    DEVIT_CHECK(q.a && q.b && q.out, DEVIT_ERR_ARG, "devit_wgrad_grouped: job %d: null pointer", j);
+    DEVIT_CHECK(q.a_cols > 0 && q.a_cols % 128 == 0 && q.lda >= q.a_cols && q.ldb >= 384 && q.lda % 8 == 0 && q.ldb % 8 == 0, DEVIT_ERR_SHAPE,
+                "devit_wgrad_grouped: job %d: a_cols=%d (a multiple of 128) lda=%d ldb=%d (>= 384 columns are read)", j, q.a_cols, q.lda, q.ldb);
+    DEVIT_CHECK(aligned16(q.a) && aligned16(q.b) && ((uintptr_t)q.out & 3) == 0 && q.ldc >= (q.transposed ? q.a_cols : 384), DEVIT_ERR_ARG,
+                "devit_wgrad_grouped: job %d: operands must be 16-byte aligned, ldc=%d too small", j, q.ldc);
+    g.job[j] = WgJob{(const __bf16*)q.a, (const __bf16*)q.b, q.out, q.a_colsum, q.lda, q.ldb, q.ldc, q.a_cols, q.transposed, tiles};
+    tiles += (q.a_cols + 255) / 256;
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    DEVIT_CHECK(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8,
+                DEVIT_ERR_DEVICE, "devit_wgrad_grouped: cannot query the CU count");
+    cus = n;
+  }
+  const int nk_total = K / BK;
+  if (split_k <= 0) {                        // one round of resident workgroups (one per CU), as many slices as give each >= 3 K-steps
+    const int avail = cus - reserved_cus() >= 8 ? cus - reserved_cus() : 8;
+    split_k = avail / tiles;
+    if (split_k < 1) split_k = 1;
+    if (split_k > nk_total / 3) split_k = nk_total / 3;
+  }
+  DEVIT_CHECK(split_k >= 1 && nk_total / split_k >= 3, DEVIT_ERR_SHAPE, "devit_wgrad_grouped: K=%d gives %d K-steps, fewer than 3 per slice at split_k=%d",
+              K, nk_total, split_k);
+  g.njobs = njobs; g.tiles = tiles; g.split = split_k; g.nk_total = nk_total; g.total = tiles * split_k;
+#ifdef DEVIT_GEMMFR_STAMP
+  g.dbg = g_wgrad_dbg;
+#else
+  g.dbg = nullptr;
+#endif
+  constexpr int lds = (256 + 384) * 128 * 2;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgradfr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr = true;
+  }
+  hipLaunchKernelGGL(wgradfr_kernel, dim3((unsigned)((g.total + 7) / 8 * 8)), dim3(256), lds, (hipStream_t)stream, g);
+  DEVIT_LAUNCH_CHECK();
+  return DEVIT_OK;
 }
 
 extern "C" int devit_set_reserved_cus(int n) {
@@ -1478,10 +1755,15 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   if (exact == 1 || (exact == 3 && M % 256 == 0 && (N % 256 == 0 || ragged_ok) && variant != 3)) cfg = exact;
   // the full-row 256x384 kernel: the student's N = 384 launches (round 5; per-shape times inside the step: profiles/r05_*).  DEVIT_GEMMFR=0 / 1
   // forces it off / on for everything it is built for (read per call: tests switch it).
-  const bool use_fr = !f16 && split_k == 1 && batch == 1 && variant == 1 && devit_gemm_full_row_selected(M, N, K, ep->kind);
+  // (the kernel addresses B densely: a row-remapped k-major B stays on the 128x128 kernel, which honours row_group / row_skip -- except with the fp32
+  // residual epilogue, which exists for a k-major B on this kernel only: refused below; DEVIT_GEMM_FORCE=1 means 128x128 tiles for everything)
+  const bool b_dense = Bop->row_group == 0 && Bop->row_skip == 0;
+  const bool use_fr = !f16 && split_k == 1 && batch == 1 && variant == 1 && b_dense && !(exact == 1 && ep->kind != DEVIT_EPI_RESIDUAL_F32) &&
+                      devit_gemm_full_row_selected(M, N, K, ep->kind);
   DEVIT_CHECK(use_fr || !(variant == 1 && ep->kind == DEVIT_EPI_RESIDUAL_F32), DEVIT_ERR_ARG,
               "devit_gemm_bf16: the fp32 residual epilogue with a k-major weight runs on the full-row kernel only (N == 384, "
-              "M %% 256 == 0, >= 64 row tiles, K >= 192, DEVIT_GEMMFR != 0): M=%d N=%d K=%d", M, N, K);
+              "M %% 256 == 0, >= 64 row tiles, K >= 192, DEVIT_GEMMFR != 0, no row_group / row_skip on B): M=%d N=%d K=%d row_group=%d", M, N, K,
+              Bop->row_group);
   if (use_fr) cfg = 4;
   const int bm = cfg == 1 ? 128 : 256, bn = cfg == 4 ? 384 : bm;
   g.tiles_m = M / bm;

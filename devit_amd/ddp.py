@@ -148,6 +148,27 @@ def _report_group(name):
     return (0, 0)
 
 
+class _ReadyHook:
+    """What BucketedGradReducer.attach() puts on the model as `grad_ready`: the report callback, plus what the encoder's backward asks when it
+    groups several blocks' weight gradients into one launch (ops.DeferredWgrads): which bucket a block's parameters travel in, and whether
+    there is an exchange to overlap at all."""
+
+    def __init__(self, reducer):
+        self.reducer = reducer
+
+    def __call__(self, params):
+        self.reducer.mark_ready(params)
+
+    world = property(lambda self: self.reducer.world)
+
+    def bucket_of(self, params):
+        for p in params:
+            i = self.reducer.flat.index.get(id(p))
+            if i is not None:
+                return self.reducer.bucket_of[i]
+        return None
+
+
 class BucketedGradReducer:
     """All-reduce (sum) of FlatParams.flat_grad in buckets, fired from `grad_ready` callbacks.
 
@@ -229,7 +250,7 @@ class BucketedGradReducer:
 
     def attach(self, model):
         """Route the model's grad_ready callbacks here (VisionTransformer.grad_ready)."""
-        model.grad_ready = self.mark_ready
+        model.grad_ready = _ReadyHook(self)
         return self
 
     def mark_ready(self, params):

@@ -73,13 +73,11 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def full_row_selected(M, N, K):
-    """The rule of csrc/gemm.hip's devit_gemm_full_row_selected(): would (row-major A) x (K-MAJOR B) with N outputs run on the full-row 256x384
-    kernel?  (A k-major weight with the fp32 residual epilogue exists on that kernel only.)"""
-    if not (M > 0 and M % 256 == 0 and N == 384 and K % 64 == 0 and K >= 192):
-        return False
-    e = os.environ.get("DEVIT_GEMMFR")
-    return (int(e) != 0) if e else M // 256 >= 64
+def full_row_selected(M, N, K, kind=L.EPI_RESIDUAL_F32):
+    """devit_gemm_full_row_selected() itself (csrc/gemm.hip; no GPU needed): would (row-major A) x (K-MAJOR B) with N outputs run on the full-row
+    256x384 kernel?  (A k-major weight with the fp32 residual epilogue exists on that kernel only.)  Not a restatement: one rule, one parser of
+    DEVIT_GEMMFR."""
+    return bool(L.load().devit_gemm_full_row_selected(M, N, K, kind))
 
 
 # Anything that rewrites 16-bit weight copies IN PLACE (behind the parameters' version counters: the fused optimizer kernel, FlatParams.refresh_bf16)
@@ -172,6 +170,58 @@ def linear_wgrad(dy, x, w_grad, b_grad, M, **kw):
          split_k=split_k_for(N, K, mp // 64), aux=b_grad, **kw)
 
 
+def wgrad_jobs_ok(mp, jobs):
+    """Can these weight gradients run as ONE launch of the full-row weight-gradient kernel (devit_wgrad_grouped)?  jobs: (dy, x, w_grad, b_grad)
+    as linear_wgrad takes them.  One side of every product must be exactly 384 features wide (the student's D), the other a multiple of 128;
+    DEVIT_WGRADFR=0 keeps the four split-K launches on 128x128 tiles."""
+    if os.environ.get("DEVIT_WGRADFR", "1") == "0" or mp % 64 or mp // 64 < 3 or len(jobs) > L.WGRAD_MAX_JOBS:
+        return False
+    tiles = 0
+    for dy, x, w_grad, _ in jobs:
+        N, K = w_grad.shape
+        if K == 384 and N % 128 == 0:
+            tiles += (N + 255) // 256
+        elif N == 384 and K % 128 == 0:
+            tiles += (K + 255) // 256
+        else:
+            return False
+    return tiles <= 256
+
+
+def linear_wgrads(jobs, M, split_k=0):
+    """The weight (and bias) gradients of several Linear layers in ONE launch: jobs = [(dy [Mp, N], x [Mp, K], w_grad [N, K], b_grad [N] or None)].
+    w_grad += dy^T x; b_grad += colsum(dy).  K == 384: tiles over dy's features; N == 384 (fc2): the product is taken transposed (tiles over x's
+    features) and its bias gradient, if asked for, comes from a column-sum pass."""
+    mp = pad_rows(M)
+    arr = (L.WgradJob * len(jobs))()
+    late = []
+    for i, (dy, x, w_grad, b_grad) in enumerate(jobs):
+        N, K = w_grad.shape
+        j = arr[i]
+        if K == 384:
+            j.a, j.lda, j.a_cols, j.b, j.ldb = dy.data_ptr(), dy.stride(0), N, x.data_ptr(), x.stride(0)
+            j.out, j.ldc, j.transposed, j.a_colsum = w_grad.data_ptr(), K, 0, _p(b_grad)
+        else:
+            j.a, j.lda, j.a_cols, j.b, j.ldb = x.data_ptr(), x.stride(0), K, dy.data_ptr(), dy.stride(0)
+            j.out, j.ldc, j.transposed, j.a_colsum = w_grad.data_ptr(), K, 1, None
+            if b_grad is not None:
+                late.append((dy, N, b_grad))
+    call("devit_wgrad_grouped", arr, len(jobs), mp, split_k, stream_ptr())
+    for dy, N, b_grad in late:
+        colsum(dy, mp, N, b_grad, True)
+
+
+# bench.py's third instrument: when PROFILE_WGRAD is a list, each grouped weight-gradient launch (DeferredWgrads.flush) is bracketed by events on
+# its stream and recorded as (algorithmic flops, algorithmic bytes, start_event, end_event)
+PROFILE_WGRAD = None
+
+
+def wgrad_enabled(mp):
+    """DEVIT_WGRADFR=0 keeps every weight gradient on the split-K 128x128 launches (read per call, as devit_block_bwd reads it)."""
+    e = os.environ.get("DEVIT_WGRADFR", "")
+    return (e == "" or int(e) != 0) and mp % 64 == 0 and mp // 64 >= 3
+
+
 def colsum(y, M, N, out, accumulate, row_group=0, row_skip=0):
     nbytes = 64 * N * 4
     ws = workspace(y.device, nbytes)
@@ -245,6 +295,76 @@ def grad_buf(p):
 def sgemm_small(A, sam, sak, Bm, sbn, sbk, bias, Cm, ldc, M, N, K, alpha=1.0, accumulate=False):
     call("devit_sgemm_small", ptr(A), sam, sak, ptr(Bm), sbn, sbk, ptr(bias), ptr(Cm), ldc, M, N, K, alpha,
          int(accumulate), stream_ptr())
+
+
+class DeferredWgrads:
+    """The weight gradients of SEVERAL blocks in one launch of the full-row weight-gradient kernel (devit_wgrad_grouped).  A block's four
+    products are 19 tiles of 256 x 384: alone they need 13 K slices to fill 256 CUs, and the slices' fp32 atomics (97 MB per block at the
+    ~1.3 TB/s the memory side adds floats at) are a third of the launch.  Grouped over g blocks the same CUs are filled by 13 / g slices:
+    the blocks' backward records its products as jobs (devit_block_bwd_io.defer_jobs / _block_backward(defer=...)) and the group is launched
+    -- and its blocks reported to `grad_ready` -- behind the backward of its last block.  Groups (DEVIT_WGRAD_GROUP=auto|all|block):
+      auto   with a gradient exchange to overlap (a reducer with world > 1 on `grad_ready`): the blocks of one reducer bucket, so that every
+             bucket still leaves as soon as its gradients exist; without one: all blocks of the encoder call (one launch, no K split)
+      all    one group        bucket  the reducer's buckets whatever the world size        block  every block alone (round 6's first form)"""
+
+    def __init__(self, cfg, nb):
+        self.cfg, self.jobs, self.pending, self.keep = cfg, [], [], []
+        hook = cfg.grad_ready
+        policy = os.environ.get("DEVIT_WGRAD_GROUP", "auto")
+        if policy not in ("auto", "all", "block", "bucket"):
+            raise L.DevitError(f"DEVIT_WGRAD_GROUP={policy!r}: auto, all, bucket or block")
+        has_buckets = getattr(hook, "bucket_of", None) is not None
+        if policy == "auto":
+            policy = "bucket" if (has_buckets and getattr(hook, "world", 1) > 1) else "all"
+        elif policy == "bucket" and not has_buckets:      # (no reducer on this model: nothing to align with)
+            policy = "all"
+        self.policy = policy
+        self.bucket = [hook.bucket_of(bp.all_params()) for bp in cfg.blocks[:nb]] if policy == "bucket" else None
+
+    def last_of_group(self, i):
+        """Is block i the last (lowest) block of its group?  (backward walks i downwards)"""
+        if i == 0 or self.policy == "block" or len(self.jobs) + 8 > L.WGRAD_MAX_JOBS:
+            return True
+        return self.policy == "bucket" and self.bucket[i] != self.bucket[i - 1]
+
+    def add(self, bp, jobs, keep=()):
+        """jobs: L.WgradJob structs of block bp, whose backward has just been enqueued; keep: whatever owns the memory they point into"""
+        self.jobs += jobs
+        self.pending.append(bp)
+        self.keep.extend(keep)
+
+    def flush(self, mp):
+        if self.jobs:
+            arr = (L.WgradJob * len(self.jobs))(*self.jobs)
+            rec = PROFILE_WGRAD
+            if rec is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            call("devit_wgrad_grouped", arr, len(self.jobs), mp, 0, stream_ptr())
+            if rec is not None:
+                e1.record()
+                cols = sum(j.a_cols for j in self.jobs)
+                rec.append((2.0 * mp * cols * 384, mp * (cols + 384 * len(self.jobs)) * 2 + cols * 384 * 4, e0, e1))
+        for bp in self.pending:
+            bp.finish_grads()
+            if self.cfg.grad_ready is not None:
+                self.cfg.grad_ready(bp.all_params())
+        self.jobs, self.pending, self.keep = [], [], []
+
+
+def wgrad_job_struct(dy, x, w_grad, b_grad):
+    """One product of linear_wgrads() as a devit_wgrad_job (None if the full-row weight-gradient kernel does not take it)."""
+    N, K = w_grad.shape
+    j = L.WgradJob()
+    if K == 384 and N % 128 == 0:
+        j.a, j.lda, j.a_cols, j.b, j.ldb = dy.data_ptr(), dy.stride(0), N, x.data_ptr(), x.stride(0)
+        j.out, j.ldc, j.transposed, j.a_colsum = w_grad.data_ptr(), K, 0, _p(b_grad)
+        return j
+    if N == 384 and K % 128 == 0 and b_grad is None:
+        j.a, j.lda, j.a_cols, j.b, j.ldb = x.data_ptr(), x.stride(0), K, dy.data_ptr(), dy.stride(0)
+        j.out, j.ldc, j.transposed, j.a_colsum = w_grad.data_ptr(), K, 1, None
+        return j
+    return None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -344,9 +464,11 @@ def _block_forward(x, bp, dp, cfg, need_grad, want_att, pad_qkv=True):
     return x2o, qkv, att, s
 
 
-def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, prev_fc2_b=None, g2_bias_done=False):
+def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, prev_fc2_b=None, g2_bias_done=False, defer=None):
     """dx: fp32 [B,N,D] grad of the block output; g2: bf16 [Mp, D] = bf16(dp2 * dx).
-    Returns (dx_in fp32 [B,N,D], g_prev bf16 [Mp,D] = bf16(prev_dp2 * dx_in) or None)."""
+    Returns (dx_in fp32 [B,N,D], g_prev bf16 [Mp,D] = bf16(prev_dp2 * dx_in) or None).
+    defer: a DeferredWgrads -- the weight gradients the full-row weight-gradient kernel takes are recorded there as jobs (the caller launches
+    them with other blocks' and then calls finish_grads / grad_ready); the others run here on the split-K 128x128 launches."""
     B, N, D = dx.shape
     M, H, dev = B * N, bp.num_heads, dx.device
     Hd = bp.fc1_w.shape[0]
@@ -355,13 +477,22 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, p
     # Order: the weight gradient that only needs g2 first, then dh_pre's producer and its consumers back to back (dh_pre is
     # 156 MB at B = 256; these GEMMs run 1.2-1.7x slower on operands from cold HBM than from the 256 MB Infinity Cache,
     # tools/gemm_bench.py COLD=1; +0.6 % on the step)
-    linear_wgrad(g2, s["h"], grad_buf(bp.fc2_w), None if g2_bias_done else grad_buf(bp.fc2_b), M)
+    js, keep = [], []
+
+    def wgrad(dy, x, w_grad, b_grad):
+        j = wgrad_job_struct(dy, x, w_grad, b_grad) if (defer is not None and wgrad_enabled(pad_rows(M))) else None
+        if j is None:
+            linear_wgrad(dy, x, w_grad, b_grad, M)
+        else:
+            js.append(j)
+            keep.extend((dy, x, w_grad, b_grad))
+    wgrad(g2, s["h"], grad_buf(bp.fc2_w), None if g2_bias_done else grad_buf(bp.fc2_b))
     dh_pre = rows_alloc(M, Hd, BF16, dev)
     linear_dgrad(g2, bp.fc2_w16, M, out=dh_pre, kind=L.EPI_DGELU_BF16, colscale=bp.neuron_gate, aux_in=s["h_pre"],
                  exact_gelu=cfg.exact_gelu)
     dln2 = rows_alloc(M, D, BF16, dev)
     linear_dgrad(dh_pre, bp.fc1_w16, M, out=dln2)
-    linear_wgrad(dh_pre, s["ln2"], grad_buf(bp.fc1_w), grad_buf(bp.fc1_b), M)
+    wgrad(dh_pre, s["ln2"], grad_buf(bp.fc1_w), grad_buf(bp.fc1_b))
     dx1 = torch.empty((B, N, D), dtype=F32, device=dev)
     g1 = rows_alloc(M, D, BF16, dev)
     fuse_pb = datt is None        # proj bias gradient = column sums of g1, produced by the same LN-bwd launch
@@ -372,7 +503,7 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, p
         g1 = g1 + _pad_like(datt, g1)
     dattn = rows_alloc(M, Da, BF16, dev)
     linear_dgrad(g1, bp.proj_w16, M, out=dattn)
-    linear_wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), None if fuse_pb else grad_buf(bp.proj_b), M)
+    wgrad(g1, s["attn_o"], grad_buf(bp.proj_w), None if fuse_pb else grad_buf(bp.proj_b))
     dqkv = rows_alloc(M, 3 * Da, BF16, dev)
     # algorithmic bytes: q, k, v, o, do in; dq, dk, dv out (+ the relation-loss gradient that is added in)
     _bracketed("attention_bwd", M * Da * 2 * (8 + (3 if dqkv_add is not None else 0)), lambda: call(
@@ -380,7 +511,9 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, p
         ptr(dqkv_add), ptr(dqkv), B, N, H, 64, 0.125, stream_ptr()))
     dln1 = rows_alloc(M, D, BF16, dev)
     linear_dgrad(dqkv, bp.qkv_w16, M, out=dln1)
-    linear_wgrad(dqkv, s["ln1"], grad_buf(bp.qkv_w), grad_buf(bp.qkv_b), M)
+    wgrad(dqkv, s["ln1"], grad_buf(bp.qkv_w), grad_buf(bp.qkv_b))
+    if defer is not None:
+        defer.add(bp, js, keep)
     dx0 = torch.empty((B, N, D), dtype=F32, device=dev)
     g_prev = rows_alloc(M, D, BF16, dev) if want_prev_g else None
     layernorm_bwd(dln1, False, s["x"].view(M, D), M, D, s["mean1"], s["rstd1"], bp.n1w, dx1.view(M, D), dx0.view(M, D),
@@ -673,21 +806,34 @@ def _encoder_backward_composite(run, cfg, dx, dqkvs):
     M, dev, nb = B * N, dx.device, run.nb
     mp = pad_rows(M)
     sz, offs, tot = _bwd_sizes(B, N, D, {(run.weights[i].attn_width, run.weights[i].hidden) for i in range(nb)})
-    # transient buffers shared by all blocks + two fp32 dx and two bf16 g buffers that alternate
-    dxb, gb = M * D * 4, mp * D * 2
-    ws = torch.empty(tot + 2 * dxb + 2 * gb, dtype=torch.uint8, device=dev)
+    defer = DeferredWgrads(cfg, nb)
+    # Workspace: the transient buffers shared by all blocks + two fp32 dx buffers that alternate + per-block SLOTS for what a deferred
+    # weight-gradient job reads (bf16 g2 = the branch gradient entering the block, dh_pre, g1, dqkv): they must outlive the block's call until
+    # its group is launched.  Groups of one block need two slots (block i reads g of slot i, writes the next block's into the other one).
+    dxb, gb = M * D * 4, (mp * D * 2 + 255) // 256 * 256
+    per = gb + sz[L.BWD_DH_PRE] + sz[L.BWD_G1] + sz[L.BWD_DQKV]
+    nslots = 2 if defer.policy == "block" else nb
+    ws = torch.empty(tot + 2 * dxb + nslots * per, dtype=torch.uint8, device=dev)
     base = ws.data_ptr()
     dx_ptrs = [base + tot, base + tot + dxb]
-    g_ptrs = [base + tot + 2 * dxb, base + tot + 2 * dxb + gb]
-    call("devit_scale_cast_bf16", ptr(dx), C.c_void_p(g_ptrs[0]), ptr(run.dps[nb - 1][1]) if run.dps is not None and run.dps[nb - 1] is not None else None,
+    slot0 = tot + 2 * dxb
+
+    def slot(i):                         # byte offsets of (g, dh_pre, g1, dqkv) of block i
+        o = slot0 + (i % nslots) * per
+        return o, o + gb, o + gb + sz[L.BWD_DH_PRE], o + gb + sz[L.BWD_DH_PRE] + sz[L.BWD_G1]
+    g_top = slot(nb - 1)[0]
+    call("devit_scale_cast_bf16", ptr(dx), C.c_void_p(base + g_top), ptr(run.dps[nb - 1][1]) if run.dps is not None and run.dps[nb - 1] is not None else None,
          N, M, D, stream_ptr())
     if mp > M:
-        ws[tot + 2 * dxb + M * D * 2: tot + 2 * dxb + gb].zero_()
+        ws[g_top + M * D * 2: g_top + mp * D * 2].zero_()
     io = L.BlockBwdIO()
     for j in range(L.BWD_COUNT):
         io.ws[j] = base + offs[j]
     io.lnws_bytes = sz[L.BWD_LNWS]
-    cur_dx, cur_g, g_bias_done = dx.data_ptr(), 0, 0
+    got = (L.WgradJob * 4)()
+    ngot = C.c_int(0)
+    io.defer_jobs, io.defer_count = C.addressof(got), C.addressof(ngot)
+    cur_dx, g_bias_done = dx.data_ptr(), 0
     st = stream_ptr()
     for i in range(nb - 1, -1, -1):
         bp = cfg.blocks[i]
@@ -695,9 +841,11 @@ def _encoder_backward_composite(run, cfg, dx, dqkvs):
         if dq is not None:
             dq = dq.contiguous()
         out_slot = (nb - 1 - i) & 1
-        io.dx, io.g2, io.dx_in = cur_dx, g_ptrs[cur_g], dx_ptrs[out_slot]
+        og, oh, o1, oq = slot(i)
+        io.dx, io.g2, io.dx_in = cur_dx, base + og, dx_ptrs[out_slot]
+        io.ws[L.BWD_DH_PRE], io.ws[L.BWD_G1], io.ws[L.BWD_DQKV] = base + oh, base + o1, base + oq
         prev = cfg.blocks[i - 1] if i > 0 else None
-        io.g_prev = g_ptrs[cur_g ^ 1] if prev is not None else None
+        io.g_prev = base + slot(i - 1)[0] if prev is not None else None
         pdp = run.dps[i - 1] if (prev is not None and run.dps is not None) else None
         io.prev_dp2 = _p(pdp[1]) if pdp is not None else None
         io.prev_fc2_b_grad = grad_buf(prev.fc2_b).data_ptr() if prev is not None else None
@@ -705,10 +853,10 @@ def _encoder_backward_composite(run, cfg, dx, dqkvs):
         io.dqkv_add = _p(dq)
         wg = _wgrads_struct(bp)
         call("devit_block_bwd", C.byref(run.weights[i]), C.byref(run.acts[i]), C.byref(wg), C.byref(io), B, N, D, cfg.eps, st)
-        cur_dx, cur_g, g_bias_done = dx_ptrs[out_slot], cur_g ^ 1, 1 if prev is not None else 0
-        bp.finish_grads()
-        if cfg.grad_ready is not None:
-            cfg.grad_ready(bp.all_params())
+        cur_dx, g_bias_done = dx_ptrs[out_slot], 1 if prev is not None else 0
+        defer.add(bp, [L.WgradJob.from_buffer_copy(got[k]) for k in range(ngot.value)], (dq,))
+        if defer.last_of_group(i):
+            defer.flush(mp)
     o = tot + (0 if cur_dx == dx_ptrs[0] else dxb)
     return ws[o:o + dxb].view(F32).view(B, N, D)
 
@@ -803,6 +951,7 @@ class EncoderFn(torch.autograd.Function):
             dx = dx + dencs[nb - 1]
         g = scale_cast(dx, saved[nb - 1]["dp2"], N)
         g_bias_done = False           # fc2 bias gradient of block i comes fused from block i+1's LN1 backward
+        defer = DeferredWgrads(cfg, nb)
         for i in range(nb - 1, -1, -1):
             bp = cfg.blocks[i]
             dq = dqkvs[i] if nq else None
@@ -813,15 +962,14 @@ class EncoderFn(torch.autograd.Function):
             extra = dencs[i - 1] if (ne and i > 0 and dencs[i - 1] is not None) else None
             fuse_prev = i > 0 and extra is None
             dx, g = _block_backward(dx, g, saved[i], bp, cfg, dq, da, prev_dp2, want_prev_g=fuse_prev,
-                                    prev_fc2_b=cfg.blocks[i - 1].fc2_b if fuse_prev else None, g2_bias_done=g_bias_done)
+                                    prev_fc2_b=cfg.blocks[i - 1].fc2_b if fuse_prev else None, g2_bias_done=g_bias_done, defer=defer)
             g_bias_done = fuse_prev
             if extra is not None:
                 dx = dx + extra
                 g = scale_cast(dx, prev_dp2, N)
             saved[i] = None
-            bp.finish_grads()
-            if cfg.grad_ready is not None:
-                cfg.grad_ready(bp.all_params())
+            if defer.last_of_group(i):
+                defer.flush(pad_rows(B * N))
         return (dx, None) + (None,) * nparams
 
 

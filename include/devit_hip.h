@@ -23,7 +23,11 @@
 extern "C" {
 #endif
 
-#define DEVIT_ABI_VERSION 1
+/* 2 (round 6): devit_block_weights grew (fc2_w16t), devit_index_copy mode 4, devit_wgrad_grouped, devit_abi_struct_size, exported symbols
+ * only (the library is built with -fvisibility=hidden).  A binding asks devit_version() AND checks its struct sizes against
+ * devit_abi_struct_size() before it passes arrays of structs (devit_encoder_fwd strides by sizeof(devit_block_weights)). */
+#define DEVIT_ABI_VERSION 2
+#define DEVIT_API __attribute__((visibility("default")))
 
 enum {
   DEVIT_OK = 0,
@@ -33,10 +37,15 @@ enum {
   DEVIT_ERR_DEVICE = -4   /* not a gfx950 device / no device */
 };
 
-int devit_version(void);
-const char* devit_last_error(void); /* host string, thread-local, valid until next call */
+DEVIT_API int devit_version(void);
+DEVIT_API const char* devit_last_error(void); /* host string, thread-local, valid until next call */
 /* 0 if device `dev` is gfx950; DEVIT_ERR_DEVICE otherwise (product path refuses to run). */
-int devit_check_device(int dev);
+DEVIT_API int devit_check_device(int dev);
+/* sizeof() of the ABI's structs as THIS library was compiled (which: 0 devit_epilogue, 1 devit_operand, 2 devit_block_weights,
+ * 3 devit_block_wgrads, 4 devit_block_acts, 5 devit_block_bwd_io, 6 devit_index_job, 7 devit_wgrad_job; anything else: 0).  A binding
+ * compares them with its own mirrors once at load time: a stale mirror of a struct that is passed as an ARRAY would otherwise be misread
+ * from its second element on, with no error. */
+DEVIT_API size_t devit_abi_struct_size(int which);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  C[M,N] = sum_k A(m,k) * B(n,k), bf16 operands, fp32 accumulate (MFMA 16x16x32).
@@ -102,14 +111,44 @@ typedef struct {
   long long batch_stride;  /* elements */
 } devit_operand;
 
-int devit_gemm_bf16(const devit_operand* A, const devit_operand* B, int M, int N, int K, int batch, int split_k,
+DEVIT_API int devit_gemm_bf16(const devit_operand* A, const devit_operand* B, int M, int N, int K, int batch, int split_k,
                     const devit_epilogue* ep, void* stream);
 /* The GEMM grids are persistent: one (256x256 tile) or two (128x128) workgroups per CU that walk their share of the tiles.
  * devit_set_reserved_cus(n) makes every later launch leave n CUs (a multiple of 8: one share per XCD) free for kernels of
  * other streams -- the RCCL all-reduce of the data-parallel step (distill_sub.py:333), whose kernels could otherwise start
  * only when a GEMM ends.  Default: the DEVIT_RESERVE_CUS environment variable, else 0.  Process-wide. */
-int devit_set_reserved_cus(int n);
-int devit_get_reserved_cus(void);
+/* Would devit_gemm_bf16 run (row-major A) x (K-MAJOR B) with N outputs and this epilogue kind on the full-row 256x384 kernel (N == 384, whole
+ * 256-row tiles and >= 64 of them, K >= 192; DEVIT_GEMMFR=0 / 1 in the environment forces it off / on)?  1 / 0.  The fp32 residual epilogue
+ * with a k-major weight exists on that kernel only, so a caller that holds a k-major copy of a forward weight (devit_block_weights.fc2_w16t)
+ * asks first. */
+DEVIT_API int devit_gemm_full_row_selected(int M, int N, int K, int kind);
+DEVIT_API int devit_set_reserved_cus(int n);
+DEVIT_API int devit_get_reserved_cus(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight gradients of several nn.Linear layers as ONE launch (autograd's dW = dY^T X of models/de_vit.py:67,82,36,45, i.e. what
+ * engine.py:123-127's backward() leaves in .grad): a table of jobs, each
+ *     out[i][j] += sum_k a[k][i] * b[k][j]      i < a_cols, j < 384           (transposed == 0: out is [a_cols][ldc])
+ *     out[j][i] += ...                                                         (transposed != 0: out is [384][ldc])
+ *     a_colsum[i] += sum_k a[k][i]              (optional: the bias gradient when a = dY)
+ * with both operands K-MAJOR as the step holds them ([K token rows][features] bf16, rows >= the real row count zero).  One operand must be
+ * exactly 384 columns wide (the student's D; fc2's gradient is taken transposed, a = the GELU output, b = dY); a_cols % 128 == 0.
+ * Kernel: 256 x 384 output tiles on the full-row tile of devit_gemm_bf16 (k-major x k-major variant, one tile and one K slice per
+ * workgroup, fp32 atomics through LDS in whole 256-byte rows); every workgroup of the table runs at once, so split_k slices x tiles
+ * should fill the device: split_k == 0 picks floor(CUs / tiles).  K % 64 == 0, K / 64 / split_k >= 3, njobs <= 48 (the four products of
+ * up to twelve blocks: devit_block_bwd_io.defer_jobs collects them).
+ * jobs is a HOST array (copied into the kernel arguments).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* a;           /* bf16 [K][lda]; a_cols columns are read (tiles of 256; a last half tile is allowed) */
+  int lda, a_cols;
+  const void* b;           /* bf16 [K][ldb]; columns 0..383 are read */
+  int ldb;
+  float* out;              /* fp32, accumulated */
+  int ldc, transposed;
+  float* a_colsum;         /* fp32 [a_cols], accumulated, or NULL */
+} devit_wgrad_job;
+DEVIT_API int devit_wgrad_grouped(const devit_wgrad_job* jobs, int njobs, int K, int split_k, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the fp32 residual stream.  Replaces nn.LayerNorm(D, eps=1e-6) at
@@ -124,11 +163,11 @@ int devit_get_reserved_cus(void);
  *   bias gradient of the Linear layer that produced the branch (saves a pass over the matrix).
  *   workspace >= devit_layernorm_bwd_workspace(rows, D).
  * ---------------------------------------------------------------------------------------- */
-int devit_layernorm_fwd(const float* x, int rows, int D, int in_group, int in_stride, const float* gamma,
+DEVIT_API int devit_layernorm_fwd(const float* x, int rows, int D, int in_group, int in_stride, const float* gamma,
                         const float* beta, float eps, void* y_bf16, float* y_f32, float* mean, float* rstd,
                         int dtype16 /* type of y_bf16: 0 bf16, 1 f16 */, void* stream);
-size_t devit_layernorm_bwd_workspace(int rows, int D);
-int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows, int D, int in_group, int in_stride,
+DEVIT_API size_t devit_layernorm_bwd_workspace(int rows, int D);
+DEVIT_API int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows, int D, int in_group, int in_stride,
                         const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
                         void* dx_bf16, const float* rowscale, int rows_per_scale, float* dgamma, float* dbeta,
                         float* dx_bf16_colsum, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
@@ -142,9 +181,9 @@ int devit_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, int rows,
  *   head_gate: f32 [H] or NULL.   head_dim must be 64, N <= 208.
  * bwd: dqkv (same layout as qkv) from dout; dqkv_add (optional, same layout) is added in.
  * ---------------------------------------------------------------------------------------- */
-int devit_attn_fwd(const void* qkv, void* out, float* lse, const float* head_gate, int B, int N, int H, int head_dim,
+DEVIT_API int devit_attn_fwd(const void* qkv, void* out, float* lse, const float* head_gate, int B, int N, int H, int head_dim,
                    float scale, int dtype16 /* type of qkv and out: 0 bf16, 1 f16 */, void* stream);
-int devit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* head_gate,
+DEVIT_API int devit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const float* head_gate,
                    const void* dqkv_add, void* dqkv, int B, int N, int H, int head_dim, float scale, void* stream);
 /* The same kernels with the query side apart from the key side: NQ <= N query rows per image against all N keys.
  * Used for the LAST block when the caller consumes only the class / distillation tokens (models/de_vit.py:286-288 reads
@@ -154,9 +193,9 @@ int devit_attn_bwd(const void* qkv, const void* out, const void* dout, const flo
  *   q   : bf16 [B*NQ][q_ld], feature h*hd + e        kv  : bf16 [B*N][kv_ld], K at feature h*hd + e, V at H*hd + h*hd + e
  *   out / dout : bf16 [B*NQ][H*hd]                    lse : f32 [B][H][NQ]
  *   dq  : bf16 [B*NQ][dq_ld]                          dkv : bf16 [B*N][dkv_ld] (dK | dV), every key row written */
-int devit_attn_fwd_rows(const void* q, int q_ld, const void* kv, int kv_ld, void* out, float* lse, const float* head_gate,
+DEVIT_API int devit_attn_fwd_rows(const void* q, int q_ld, const void* kv, int kv_ld, void* out, float* lse, const float* head_gate,
                         int B, int NQ, int N, int H, int head_dim, float scale, int dtype16, void* stream);
-int devit_attn_bwd_rows(const void* q, int q_ld, const void* kv, int kv_ld, const void* out, const void* dout,
+DEVIT_API int devit_attn_bwd_rows(const void* q, int q_ld, const void* kv, int kv_ld, const void* out, const void* dout,
                         const float* lse, const float* head_gate, void* dq, int dq_ld, void* dkv, int dkv_ld, int B, int NQ,
                         int N, int H, int head_dim, float scale, void* stream);
 
@@ -228,11 +267,16 @@ typedef struct {
   const void* dqkv_add;    /* bf16, qkv layout, or NULL */
   void* ws[DEVIT_BWD_COUNT];
   size_t lnws_bytes;
+  devit_wgrad_job* defer_jobs; /* HOST array of >= 4 entries or NULL.  Not NULL: the block's weight gradients that can run on the full-row
+                                  weight-gradient kernel are NOT launched; they are written here as jobs for a later devit_wgrad_grouped call
+                                  (several blocks in one launch: fewer K slices, fewer atomics).  The caller then keeps io->g2 and the
+                                  DH_PRE / G1 / DQKV transients (and the forward's activations) alive until that launch has been enqueued */
+  int* defer_count;            /* out: jobs written */
 } devit_block_bwd_io;
 
-int devit_block_acts_sizes(int B, int N, int D, int attn_width, int hidden, int flags, size_t* sizes /* [DEVIT_ACT_COUNT] */);
-int devit_block_bwd_sizes(int B, int N, int D, int attn_width, int hidden, size_t* sizes /* [DEVIT_BWD_COUNT] */);
-int devit_encoder_fwd(int nblocks, const devit_block_weights* w, const devit_block_acts* acts, int B, int N, int D,
+DEVIT_API int devit_block_acts_sizes(int B, int N, int D, int attn_width, int hidden, int flags, size_t* sizes /* [DEVIT_ACT_COUNT] */);
+DEVIT_API int devit_block_bwd_sizes(int B, int N, int D, int attn_width, int hidden, size_t* sizes /* [DEVIT_BWD_COUNT] */);
+DEVIT_API int devit_encoder_fwd(int nblocks, const devit_block_weights* w, const devit_block_acts* acts, int B, int N, int D,
                       float eps, void* stream);
 /* devit_block_bwd is the ONE entry point that does not keep to "enqueue on the caller's stream only": its four weight-gradient GEMMs go to a
  * stream the LIBRARY owns -- one non-blocking stream + five events per device, created at the first call on that device (thread-safe), never
@@ -243,7 +287,7 @@ int devit_encoder_fwd(int nblocks, const devit_block_weights* w, const devit_blo
  * the side stream exists (first call outside capture); (2) a stream-ordered allocator must treat the buffers of `acts` / `io` / `grads` as in use
  * until work enqueued on `stream` AFTER the call has run (they are read by another stream meanwhile); (3) DEVIT_WGRAD_STREAM=0 in the environment
  * (read per call) keeps every launch on `stream`; a device index >= 16 does the same.  Worth +0.9 % on the DEKD step (profiles/r04_h_*). */
-int devit_block_bwd(const devit_block_weights* w, const devit_block_acts* acts, const devit_block_wgrads* grads,
+DEVIT_API int devit_block_bwd(const devit_block_weights* w, const devit_block_acts* acts, const devit_block_wgrads* grads,
                     const devit_block_bwd_io* io, int B, int N, int D, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -267,7 +311,7 @@ typedef struct {
   int mode;
   int elem;              /* bytes per element: 2 or 4 (modes 2, 3: 4) */
 } devit_index_job;
-int devit_index_copy(const devit_index_job* jobs_device, int njobs, int blocks_per_job, void* stream);
+DEVIT_API int devit_index_copy(const devit_index_job* jobs_device, int njobs, int blocks_per_job, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch embedding helpers (timm PatchEmbed used at models/de_vit.py:166-168,258 and token assembly
@@ -277,37 +321,37 @@ int devit_index_copy(const devit_index_job* jobs_device, int njobs, int blocks_p
  * embed_bwd: dpos[T][D] = sum_b dx[b]; dcls = dpos[0]; ddist = dpos[1]; dbias = sum_{t>=ntok} dpos[t];
  *   dx_bf16 (optional) = bf16 copy of dx for the patch-projection wgrad.
  * ---------------------------------------------------------------------------------------- */
-int devit_im2row_bf16(const float* img, void* rows, int B, int C, int H, int W, int patch, int dtype16, void* stream);
+DEVIT_API int devit_im2row_bf16(const float* img, void* rows, int B, int C, int H, int W, int patch, int dtype16, void* stream);
 /* On-device input stage (engine.py:65-66: timm Mixup(mode='batch') on the fp32 batch, then patch_embed): the mixed batch is
  * produced directly as the bf16 patch rows both models' patch-embedding GEMMs read -- one pass over the images.
  *   mode 0: plain im2row; 1: mixup  lam * x + (1 - lam) * x.flip(0);  2: cutmix  x[:, :, y0:y1, x0:x1] = x.flip(0)[...]
  *   (lam, the box and the mixup / cutmix draw are host-side numpy RNG in timm; they are arguments here).
  * devit_mix_targets: [B][C] f32 = lam * smooth_one_hot(y) + (1 - lam) * smooth_one_hot(y.flip(0)), int64 labels. */
-int devit_mix_im2row_bf16(const float* img, void* rows /* bf16 or NULL */, void* rows_f16 /* f16 or NULL */, int B, int mode,
+DEVIT_API int devit_mix_im2row_bf16(const float* img, void* rows /* bf16 or NULL */, void* rows_f16 /* f16 or NULL */, int B, int mode,
                           double lam, int y0, int y1, int x0, int x1, void* stream);
-int devit_mix_targets(const long long* labels, float* targets, int B, int C, double lam, double smoothing, void* stream);
-int devit_embed_tokens(const float* cls, const float* dist, const float* pos, float* x, int B, int T, int D,
+DEVIT_API int devit_mix_targets(const long long* labels, float* targets, int B, int C, double lam, double smoothing, void* stream);
+DEVIT_API int devit_embed_tokens(const float* cls, const float* dist, const float* pos, float* x, int B, int T, int D,
                        void* stream);
-int devit_embed_bwd(const float* dx, int B, int T, int D, int ntok, float* dpos, float* dcls, float* ddist,
+DEVIT_API int devit_embed_bwd(const float* dx, int B, int T, int D, int ntok, float* dpos, float* dcls, float* ddist,
                     float* dbias, void* dx_bf16, int accumulate, void* stream);
 
 /* f32 -> bf16 cast of a flat buffer (weights, once per optimizer step). */
-int devit_cast_bf16(const float* src, void* dst, size_t n, int dtype16, void* stream);
+DEVIT_API int devit_cast_bf16(const float* src, void* dst, size_t n, int dtype16, void* stream);
 
 /* dst_bf16[m][d] = bf16(src[m][d] * (rowscale ? rowscale[m / rows_per_scale] : 1)): turns the fp32
  * residual-stream gradient into the bf16 branch gradient (DropPath scale folded, de_vit.py:114-115). */
-int devit_scale_cast_bf16(const float* src, void* dst, const float* rowscale, int rows_per_scale, int M, int D,
+DEVIT_API int devit_scale_cast_bf16(const float* src, void* dst, const float* rowscale, int rows_per_scale, int M, int D,
                           void* stream);
 
 /* Column sums of a bf16 [M][ld] matrix: out[n] (+)= sum_m y[m][n]  (bias gradients of nn.Linear).
  * row_group/row_skip as in devit_operand.  workspace >= devit_colsum_workspace(M, N). */
-size_t devit_colsum_workspace(int M, int N);
-int devit_colsum_bf16(const void* y, int M, int N, int ld, int row_group, int row_skip, float* out, int accumulate,
+DEVIT_API size_t devit_colsum_workspace(int M, int N);
+DEVIT_API int devit_colsum_bf16(const void* y, int M, int N, int ld, int row_group, int row_skip, float* out, int accumulate,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Small strided f32 GEMM  C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + bias[n].
  * Classifier heads (models/de_vit.py:317) and their backward; exact fp32 FMA chain. */
-int devit_sgemm_small(const float* A, long long sam, long long sak, const float* B, long long sbn, long long sbk,
+DEVIT_API int devit_sgemm_small(const float* A, long long sam, long long sak, const float* B, long long sbn, long long sbk,
                       const float* bias, float* C, int ldc, int M, int N, int K, float alpha, int accumulate,
                       void* stream);
 
@@ -321,9 +365,9 @@ int devit_sgemm_small(const float* A, long long sam, long long sak, const float*
  * create_optimizer's second parameter group: 1-D tensors, biases, model.no_weight_decay(); distill_sub.py:340); NULL =
  * decay everywhere.  grad_scale: the 1 / world_size of the data-parallel mean (the buckets are all-reduced as sums).
  * ---------------------------------------------------------------------------------------- */
-size_t devit_sumsq_workspace(void);
-int devit_sumsq_f32(const float* g, size_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
-int devit_adamw_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+DEVIT_API size_t devit_sumsq_workspace(void);
+DEVIT_API int devit_sumsq_f32(const float* g, size_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
+DEVIT_API int devit_adamw_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
                      const unsigned char* no_decay4, const float* gnorm_sq, const float* dyn, size_t n, float beta1,
                      float beta2, float eps, float weight_decay, float max_norm, float ema_decay, float grad_scale,
                      void* stream);
@@ -334,13 +378,13 @@ int devit_adamw_step(float* p, const float* g, float* m, float* v, float* ema, v
  *   kind: 0 none, 1 soft (KL, tau), 2 hard (CE vs argmax of teacher logits, ties -> lowest index)
  *   loss3 = {total, base, distill};  dlogits / dlogits_kd = d total / d logits (upstream grad 1).
  * ---------------------------------------------------------------------------------------- */
-int devit_cls_distill_loss(const float* logits, const float* logits_kd, const float* teacher_logits,
+DEVIT_API int devit_cls_distill_loss(const float* logits, const float* logits_kd, const float* teacher_logits,
                            const float* soft_targets, int B, int C, int kind, float alpha, float tau, float* loss3,
                            float* dlogits, float* dlogits_kd, void* stream);
 
 /* Token feature-matching loss of the ensemble stage (EnsLoss, utils/losses.py:194,228,241-242: nn.MSELoss):
  * loss[0] (+)= mean((a - b)^2); da (optional) = 2 (a - b) / n. */
-int devit_token_mse(const float* a, const float* b, size_t n, float* loss, float* da, int accumulate, void* stream);
+DEVIT_API int devit_token_mse(const float* a, const float* b, size_t n, float* loss, float* da, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * q/k/v feature-relation loss (utils/losses.py:307-328).  The per-image Grams F F^T run on
@@ -350,9 +394,9 @@ int devit_token_mse(const float* a, const float* b, size_t n, float* loss, float
  * grad : S = G + G^T, G = (softmax_s - softmax_t) * upstream / (B sqrt(hd_s)), bf16 [B][256][256],
  *        zero outside N x N; then dF_student = S F_student on devit_gemm_bf16.
  * ---------------------------------------------------------------------------------------- */
-int devit_relation_stats(const float* gram_t, const float* gram_s, int B, int N, int ldr, int head_dim_t,
+DEVIT_API int devit_relation_stats(const float* gram_t, const float* gram_s, int B, int N, int ldr, int head_dim_t,
                          int head_dim_s, float* lse_t, float* lse_s, float* row_kl, float* loss, void* stream);
-int devit_relation_grad(const float* gram_t, const float* gram_s, const float* lse_t, const float* lse_s,
+DEVIT_API int devit_relation_grad(const float* gram_t, const float* gram_s, const float* lse_t, const float* lse_s,
                         const float* upstream, int B, int N, int ldr, int head_dim_t, int head_dim_s, void* S_out,
                         int out_is_f32, void* stream);
 
@@ -368,16 +412,16 @@ int devit_relation_grad(const float* gram_t, const float* gram_s, const float* l
  *   devit_softmax_rows_f32 / devit_softmax_bwd_rows_f32: in-place row softmax of scale*S (+ natural-log LSE) and
  *     its backward dS = scale * P * (dP - sum_j P dP): with the GEMM above they restate de_vit.py:70-74.
  * ---------------------------------------------------------------------------------------- */
-int devit_gemm_f32(const float* A, long long sam, long long sak, long long a_bs_outer, long long a_bs_inner,
+DEVIT_API int devit_gemm_f32(const float* A, long long sam, long long sak, long long a_bs_outer, long long a_bs_inner,
                    const float* B, long long sbn, long long sbk, long long b_bs_outer, long long b_bs_inner, int M, int N,
                    int K, int batch, int batch_inner, long long c_bs_outer, long long c_bs_inner, int k_group, int k_skip,
                    float alpha, const float* batch_scale, int accumulate, const devit_epilogue* ep, void* stream);
-int devit_softmax_rows_f32(float* S, int rows, int ncols, int ld, float scale, float* lse, void* stream);
-int devit_softmax_bwd_rows_f32(const float* P, float* dP, int rows, int ncols, int ld, float scale, void* stream);
-int devit_im2row_f32(const float* img, float* rows, int B, void* stream);
-int devit_scale_rows_f32(const float* src, float* dst, const float* rowscale, int rows_per_scale, int M, int D,
+DEVIT_API int devit_softmax_rows_f32(float* S, int rows, int ncols, int ld, float scale, float* lse, void* stream);
+DEVIT_API int devit_softmax_bwd_rows_f32(const float* P, float* dP, int rows, int ncols, int ld, float scale, void* stream);
+DEVIT_API int devit_im2row_f32(const float* img, float* rows, int B, void* stream);
+DEVIT_API int devit_scale_rows_f32(const float* src, float* dst, const float* rowscale, int rows_per_scale, int M, int D,
                          void* stream);
-int devit_colsum_f32(const float* y, int M, int N, int ld, float* out, int accumulate, void* stream);
+DEVIT_API int devit_colsum_f32(const float* y, int M, int N, int ld, float* out, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gradient exchange of the data-parallel step (distill_sub.py:333: DistributedDataParallel's reducer):
@@ -390,10 +434,10 @@ int devit_colsum_f32(const float* y, int M, int N, int ld, float* out, int accum
  *     the caller scales by 1/world (devit_adamw_step's grad_scale) -- one bucket of the flat gradient buffer per call.
  * ---------------------------------------------------------------------------------------- */
 #define DEVIT_COMM_ID_BYTES 128
-int devit_comm_unique_id(void* id /* [DEVIT_COMM_ID_BYTES] host */);
-int devit_comm_init(const void* id, int rank, int world, void** comm);
-int devit_comm_allreduce_f32(void* comm, float* buf, size_t count, void* stream);
-int devit_comm_destroy(void* comm);
+DEVIT_API int devit_comm_unique_id(void* id /* [DEVIT_COMM_ID_BYTES] host */);
+DEVIT_API int devit_comm_init(const void* id, int rank, int world, void** comm);
+DEVIT_API int devit_comm_allreduce_f32(void* comm, float* buf, size_t count, void* stream);
+DEVIT_API int devit_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

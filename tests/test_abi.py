@@ -39,7 +39,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.devit_version() == 1
+    assert lib.devit_version() == 2
     assert isinstance(lib.devit_last_error(), bytes)
 
 
@@ -155,21 +155,32 @@ def test_gemmfr_inc_is_current(tmp_path):
     assert out.read_bytes() == open(os.path.join(ROOT, "devit_amd", "csrc", "gemmfr_kloop.inc"), "rb").read()
 
 
-def test_full_row_rule_is_mirrored(monkeypatch):
-    """ops.full_row_selected() restates csrc/gemm.hip's devit_gemm_full_row_selected() (the host decides with it whether to hand the GEMM a
-    k-major weight): the two must agree -- checked against the C++ source's constants."""
+def test_full_row_rule_is_the_library_s(lib, monkeypatch):
+    """ops.full_row_selected() CALLS csrc/gemm.hip's devit_gemm_full_row_selected() (the host decides with it whether to hand the GEMM a
+    k-major weight): one rule, one parser of DEVIT_GEMMFR (advisor r05: the Python restatement read "" and non-numeric values differently)."""
     from devit_amd import ops
-    src = open(os.path.join(ROOT, "devit_amd", "csrc", "gemm.hip")).read()
-    body = src[src.index("bool devit_gemm_full_row_selected"):]
-    body = body[:body.index("\n}\n")]
-    assert "M % 256 == 0 && N == 384" in body and "K / BK >= 3" in body and "M / 256 >= 64" in body and 'getenv("DEVIT_GEMMFR")' in body
     monkeypatch.delenv("DEVIT_GEMMFR", raising=False)
     assert ops.full_row_selected(50688, 384, 1536) and ops.full_row_selected(16384, 384, 192)
     assert not ops.full_row_selected(512, 384, 1536) and not ops.full_row_selected(50688, 768, 768) and not ops.full_row_selected(50688, 384, 128)
+    assert not ops.full_row_selected(50688, 384, 1536, kind=1)          # GELU epilogue: not built on that kernel
+    monkeypatch.setenv("DEVIT_GEMMFR", "")                              # empty = unset
+    assert ops.full_row_selected(50688, 384, 1536) and not ops.full_row_selected(512, 384, 1536)
     monkeypatch.setenv("DEVIT_GEMMFR", "0")
     assert not ops.full_row_selected(50688, 384, 1536)
     monkeypatch.setenv("DEVIT_GEMMFR", "1")
     assert ops.full_row_selected(512, 384, 1536)
+    monkeypatch.setenv("DEVIT_GEMMFR", "x")                             # atoi: 0
+    assert not ops.full_row_selected(50688, 384, 1536)
+
+
+def test_struct_sizes_match_the_library(lib):
+    """ctypes mirrors vs sizeof() in the compiled library (advisor r05: devit_block_weights grew a field under an unchanged version number;
+    devit_encoder_fwd strides an ARRAY of them)."""
+    import ctypes as C
+    from devit_amd import _lib
+    for which, cls in _lib.ABI_STRUCTS.items():
+        assert lib.devit_abi_struct_size(which) == C.sizeof(cls), (which, cls.__name__)
+    assert lib.devit_abi_struct_size(99) == 0
 
 
 def test_build_gate_sees_agpr_writes():

@@ -239,6 +239,55 @@ def test_gemm_wgrad_fused_bias_grad(dev, rows, N, K, split):
     assert relerr(bg, dy.float().sum(0)) < 2e-5
 
 
+def _int_bf16(shape, seed, dev, lo=-3, hi=4):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).to(BF16).to(dev)
+
+
+@pytest.mark.parametrize("rows,split", [(16384, 0), (4096, 5), (192 * 64, 64)])
+def test_wgrad_grouped_exact_integers(dev, rows, split):
+    """devit_wgrad_grouped (the full-row weight-gradient kernel, k-major x k-major): the four products of a student block in ONE launch --
+    qkv (1152 outputs: 4.5 tiles), proj (384: 1.5 tiles), fc1 (1536) and fc2 TRANSPOSED (tiles over the hidden features) -- with
+    integer-valued operands: every product and every fused bias gradient must be EXACT, on top of what the accumulators held."""
+    from devit_amd import ops
+    D, Hd = 384, 1536
+    dqkv, ln1 = _int_bf16((rows, 3 * D), 1, dev), _int_bf16((rows, D), 2, dev)
+    g1, ao = _int_bf16((rows, D), 3, dev), _int_bf16((rows, D), 4, dev)
+    dh, ln2 = _int_bf16((rows, Hd), 5, dev), _int_bf16((rows, D), 6, dev)
+    g2, h = _int_bf16((rows, D), 7, dev), _int_bf16((rows, Hd), 8, dev)
+    gw = [torch.full(sh, 3.0, dtype=F32, device=dev) for sh in ((3 * D, D), (D, D), (Hd, D), (D, Hd))]
+    gb = [torch.full((n,), -2.0, dtype=F32, device=dev) for n in (3 * D, D, Hd, D)]
+    jobs = [(dqkv, ln1, gw[0], gb[0]), (g1, ao, gw[1], None), (dh, ln2, gw[2], gb[2]), (g2, h, gw[3], gb[3])]
+    assert ops.wgrad_jobs_ok(rows, jobs)
+    ops.linear_wgrads(jobs, rows, split_k=split)
+    torch.cuda.synchronize()
+    for (dy, x, w, b), name in zip(jobs, ("qkv", "proj", "fc1", "fc2")):
+        ref = dy.float().t() @ x.float() + 3.0
+        assert torch.equal(w, ref), (name, float((w - ref).abs().max()))
+        if b is not None:
+            assert torch.equal(b, dy.float().sum(0) - 2.0), name
+    assert bool((gb[1] == -2.0).all())
+
+
+def test_wgrad_grouped_random_and_compact_shapes(dev):
+    """Random data against the fp32 product (summation-order noise only), on the compacted student's shapes: hidden 1152, attention width 256
+    (qkv 768 outputs; proj's product transposed: tiles over its 256 input features), leading dimensions wider than the columns read."""
+    from devit_amd import ops
+    rows, D = 8192, 384
+    dqkv, ln1 = rnd((rows, 768), dev, seed=1, dtype=BF16), rnd((rows, D), dev, seed=2, dtype=BF16)
+    g1, ao = rnd((rows, D), dev, seed=3, dtype=BF16), rnd((rows, 512), dev, seed=4, dtype=BF16)[:, :256]     # ld 512, 256 columns read
+    dh, ln2 = rnd((rows, 1152), dev, seed=5, dtype=BF16), rnd((rows, D), dev, seed=6, dtype=BF16)
+    g2, h = rnd((rows, D), dev, seed=7, dtype=BF16), rnd((rows, 1152), dev, seed=8, dtype=BF16)
+    gw = [torch.zeros(sh, dtype=F32, device=dev) for sh in ((768, D), (D, 256), (1152, D), (D, 1152))]
+    gb = [torch.zeros(n, dtype=F32, device=dev) for n in (768, D, 1152, D)]
+    jobs = [(dqkv, ln1, gw[0], gb[0]), (g1, ao, gw[1], gb[1]), (dh, ln2, gw[2], gb[2]), (g2, h, gw[3], None)]
+    ops.linear_wgrads(jobs, rows)
+    for (dy, x, w, b), name in zip(jobs, ("qkv", "proj", "fc1", "fc2")):
+        assert relerr(w, dy.float().t() @ x.float()) < 2e-5, name
+        if b is not None:
+            assert relerr(b, dy.float().sum(0)) < 2e-5, name
+
+
 def test_gemm_layout_asymmetric(dev):
     """A = I-like selector with an asymmetric B catches swapped row/col maps (cdna guide §3)."""
     from devit_amd import ops, _lib as L

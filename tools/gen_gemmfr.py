@@ -51,6 +51,21 @@ Operands of the asm statement (named; declared in gemmfr_kernel):
             2 (chunk group & 3) + (n-tile & 1) -- see b_reads()
   [dmaa0..3] v per-lane source byte offsets of A slabs 0..3 (4..7 = + lda64)
   [dmab0..11] v of this wave's twelve B slabs, relative to its first k row (16 k rows per wave)
+
+The WEIGHT-GRADIENT variant (round 6: DEVIT_WGRADFR_KLOOP_ASM, wgradfr_kernel in gemm.hip; KMA = True below): the A operand is K-MAJOR as
+well (dW = dY^T X: both operands are [K token rows][features]), one tile and one K slice per workgroup (no next tile), column sums of A
+on the side.  What changes against the PAIRED variant above, and nothing else does (same ring protocol, phases, waits, request gaps):
+  * A slot image [64 k][256 cols] (512-byte rows, swz_krow); the wave requests its 16 k rows as eight 1-KiB slabs of two k rows
+    ([dmaa0..7], one pointer, [ldas] = 64 lda 2 bytes per stage);
+  * A fragments by two ds_read_b64_tr_b16 per tile, PAIRED column order on the A side too (tile i, MFMA column c = tile row
+    32 (i >> 1) + 8 (c >> 2) + 4 (i & 1) + (c & 3) of the wave's 128): with x = 4 wm + (i >> 1) the address inside the slot is
+    512 krow + 64 (x ^ q4) + 16 (p ^ 2 (G & 1)) + 8 (i & 1) -> FOUR base registers [t0..t3] by i >> 1 ([dsa0..3]); the k-half (16384), i & 1
+    and the second read (2048) are immediates.  B reads use [t4..t7] / [dsb0..3];
+  * two reads per A tile: the counted lgkmcnt in front of MFMA (7, 0) leaves 14 reads in flight, pending_after_b() counts A[7] twice;
+  * column sums of A (= the bias gradient when A = dY): wave (wm, wn) adds up its A tiles with (i & 1) == wn -- four v_dot2c_f32_bf16 of
+    the fragment registers against [ones] (0x3f803f80, or 0: no sums wanted) into [rs0..3], behind the first MFMAs of row i (the fragment
+    has landed, its re-read is issued behind the row's last MFMA).  Lane (G, c) ends with the sum over ITS k of tile row c: the kernel
+    folds the four G.
 """
 import os
 import sys
@@ -87,11 +102,22 @@ def fb(q, half=None):
     return f"v[{FB + 4 * q + 2 * half}:{FB + 4 * q + 2 * half + 1}]"
 
 
-def a_read(i):
-    return f"ds_read_b128 {fa(i)}, %[t{i & 1}] offset:{4096 * (i >> 1)}"
+def a_read(i, kk=0):
+    """fragment of A tile i for k-half kk -> list of LDS reads (row-major A: the k-half is in the address registers; k-major: an immediate)"""
+    if KMA:
+        off = 16384 * kk + 8 * (i & 1)
+        return [f"ds_read_b64_tr_b16 v[{FA + 4 * i}:{FA + 4 * i + 1}], %[t{i >> 1}] offset:{off}",
+                f"ds_read_b64_tr_b16 v[{FA + 4 * i + 2}:{FA + 4 * i + 3}], %[t{i >> 1}] offset:{off + 2048}"]
+    return [f"ds_read_b128 {fa(i)}, %[t{i & 1}] offset:{4096 * (i >> 1)}"]
+
+
+def a_reads_per_tile():
+    return 2 if KMA else 1
 
 
 PAIRED = True      # column order of the n-tiles: tile_row<PAIRED>() in gemm.hip (bf16 store: PAIRED, fp32 residual: natural)
+KMA = False        # the weight-gradient variant: A k-major too, column sums of A, no next tile (see the docstring)
+TB = 2             # first [t] register of the B read addresses (KMA: 4 -- A takes t0..t3)
 
 
 def b_reads(q, half, wave):
@@ -104,19 +130,25 @@ def b_reads(q, half, wave):
     x = 6 * (wave & 1) + (q >> 1)
     off = half * 32 * 768 + 64 * (x & ~3)
     if PAIRED:
-        t, off = 2 + (x & 3), off + 8 * (q & 1)
+        t, off = TB + (x & 3), off + 8 * (q & 1)
     else:
-        t = 2 + 2 * (x & 3) + (q & 1)
+        t = TB + 2 * (x & 3) + (q & 1)
     return [f"ds_read_b64_tr_b16 {fb(q, 0)}, %[t{t}] offset:{off}", f"ds_read_b64_tr_b16 {fb(q, 1)}, %[t{t}] offset:{off + 4 * 768}"]
 
 
 def addr_setup(kk, a_sreg, b_sreg):
+    if KMA:
+        return ([f"v_add_u32 %[t{x}], s{a_sreg}, %[dsa{x}]" for x in range(4)] +
+                [f"v_add_u32 %[t{TB + x}], s{b_sreg}, %[dsb{x}]" for x in range(4)])
     return ([f"v_add_u32 %[t0], s{a_sreg}, %[dsa{2 * kk}]", f"v_add_u32 %[t1], s{a_sreg}, %[dsa{2 * kk + 1}]"] +
             [f"v_add_u32 %[t{2 + x}], s{b_sreg}, %[dsb{x}]" for x in range(4 if PAIRED else 8)])
 
 
 def requests_a():
     out = []
+    if KMA:
+        return [(f"s_add_u32 m0, s{S['dstA']}, {i * 1024}", f"global_load_lds_dwordx4 %[dmaa{i}], s[{S['pa']}:{S['pa'] + 1}]" + (" nt" if A_NT else ""))
+                for i in range(8)]
     for i in range(8):
         base = S["pa"] if i < 4 else S["pa1"]
         out.append((f"s_add_u32 m0, s{S['dstA']}, {i * 1024}", f"global_load_lds_dwordx4 %[dmaa{i & 3}], s[{base}:{base + 1}]" + (" nt" if A_NT else "")))
@@ -133,6 +165,8 @@ def derive_pa1():
 
 def advance_a():
     """after an A stage was requested: 128 bytes along the rows.  Units of (s_add, s_addc): a unit never straddles an M0 write (SCC)."""
+    if KMA:      # 64 k rows further
+        return [[f"s_add_u32 s{S['pa']}, s{S['pa']}, %[ldas]", f"s_addc_u32 s{S['pa'] + 1}, s{S['pa'] + 1}, 0"]]
     return [[f"s_add_u32 s{S['pa']}, s{S['pa']}, 128", f"s_addc_u32 s{S['pa'] + 1}, s{S['pa'] + 1}, 0"], derive_pa1()]
 
 
@@ -153,14 +187,14 @@ def swap(a, b):
 
 def pending_after_b(q):
     """LDS reads issued after the last read of B[q] in the phase before: the later B tiles (two reads each) and A[7]"""
-    return 2 * (NQ - 1 - q) + 1
+    return 2 * (NQ - 1 - q) + a_reads_per_tile()
 
 
-def phase(e, wave, zero, reads, reqs, vmcnt, units_head, units_tail):
+def phase(e, wave, zero, reads, reqs, vmcnt, units_head, units_tail, akk=0):
     """96 MFMAs of one k-half, row by row; everything else dealt into the gaps (gap n = behind MFMA n).
     reads: None or the half of the B slot the next phase's B fragments come from.  vmcnt: the count of the barrier's wait.
     units_head: units for the gaps from 0 on (read addresses, request destination), units_tail: for the gaps from 84 on (pointer /
-    slot bookkeeping), one unit per gap."""
+    slot bookkeeping), one unit per gap.  akk: the k-half of the A fragments read for the NEXT phase (an immediate of the k-major reads)."""
     rgap = {}
     if reqs and not NOREQ:
         stride = (NM - NQ - 13 - 4) // len(reqs)            # 12 requests: every 5 gaps, 8: every 8
@@ -177,12 +211,14 @@ def phase(e, wave, zero, reads, reqs, vmcnt, units_head, units_tail):
             if i == 0:
                 e(f"s_waitcnt lgkmcnt({min(15, pending_after_b(q))})")
             if i == NI - 1 and q == 0:
-                e(f"s_waitcnt lgkmcnt({NI - 1 if reads is not None else 0})")
+                e(f"s_waitcnt lgkmcnt({a_reads_per_tile() * (NI - 1) if reads is not None else 0})")
             c = "0" if zero else acc(i, q)
             e(f"v_mfma_f32_16x16x32_bf16 {acc(i, q)}, {fb(q)}, {fa(i)}, {c}")
             if n < len(units_head):
                 for s in units_head[n]:
                     e(s)
+            if KMA and (i & 1) == (wave & 1) and 1 <= q <= 4:    # column sums of A: this wave's tiles, behind the row's first MFMAs
+                e(f"v_dot2c_f32_bf16 %[rs{i >> 1}], %[ones], v{FA + 4 * i + q - 1}")
             if n == BAR_GAP:
                 vm_split = STAMP and os.environ.get("GEMMFR_STAMP_VM") == "1"   # experiment: d2 = the vmcnt wait alone, d1 = the barrier alone
                 if STAMP:
@@ -214,12 +250,14 @@ def phase(e, wave, zero, reads, reqs, vmcnt, units_head, units_tail):
                     e(f"s_add_u32 s{ST['d2']}, s{ST['d2']}, s{ST['t1'] + 1}")
             if reads is not None:
                 if q == NQ - 1 and i < NI - 1:
-                    e(a_read(i))
+                    for s in a_read(i, akk):
+                        e(s)
                 if i == NI - 1:
                     for s in b_reads(q, reads, wave):
                         e(s)
                     if q == NQ - 1:
-                        e(a_read(NI - 1))
+                        for s in a_read(NI - 1, akk):
+                            e(s)
             for s in rgap.get(n, []):
                 e(s)
             if n >= NM - NQ and n - (NM - NQ) < len(units_tail):
@@ -234,12 +272,12 @@ def step(e, wave, kind, req_b, req_a, vm_even, vm_odd):
     # even phase: reads A (s, 1) from the current A slot and B (s + 1, half 0) from the other B slot; requests B (s + 2) into the current B slot
     head = [[s] for s in addr_setup(1, S["acur"], S["bnxt"])] + [[f"s_add_u32 s{S['dstB']}, s{S['bcur']}, %[wldsb]"]]
     tail = (advance_b() if req_b and "b" not in FIXSRC else []) + [swap("bcur", "bnxt")]
-    phase(e, wave, kind == "first", 0, requests_b() if req_b else None, vm_even, head, tail)
+    phase(e, wave, kind == "first", 0, requests_b() if req_b else None, vm_even, head, tail, akk=1)
     # odd phase: reads A (s + 1, 0) from the other A slot and B (s + 1, half 1) from the (now) current B slot; requests A (s + 2)
     last = kind == "last"
     head = ([[s] for s in addr_setup(0, S["anxt"], S["bcur"])] if not last else []) + [[f"s_add_u32 s{S['dstA']}, s{S['acur']}, %[wldsa]"]]
     tail = (advance_a() if req_a and "a" not in FIXSRC else []) + [swap("acur", "anxt")]
-    phase(e, wave, False, None if last else 1, requests_a() if req_a else None, vm_odd, head, tail)
+    phase(e, wave, False, None if last else 1, requests_a() if req_a else None, vm_odd, head, tail, akk=0)
 
 
 def kloop():
@@ -252,10 +290,15 @@ def kloop():
     # request pointers start at stage 2 (stages 0 and 1 of this tile were requested by the previous tile's last steps, or by the
     # kernel's prologue)
     e(f"s_mov_b64 s[{S['pa']}:{S['pa'] + 1}], %[aptr]")
-    e(f"s_add_u32 s{S['pa']}, s{S['pa']}, 256")
-    e(f"s_addc_u32 s{S['pa'] + 1}, s{S['pa'] + 1}, 0")
-    for s in derive_pa1():
-        e(s)
+    if KMA:
+        for _ in range(2):
+            e(f"s_add_u32 s{S['pa']}, s{S['pa']}, %[ldas]")
+            e(f"s_addc_u32 s{S['pa'] + 1}, s{S['pa'] + 1}, 0")
+    else:
+        e(f"s_add_u32 s{S['pa']}, s{S['pa']}, 256")
+        e(f"s_addc_u32 s{S['pa'] + 1}, s{S['pa'] + 1}, 0")
+        for s in derive_pa1():
+            e(s)
     e(f"s_mov_b32 s{S['bv']}, %[bv2]")
     for s in b_pointer():
         e(s)
@@ -278,7 +321,8 @@ def kloop():
         for s in addr_setup(0, S["acur"], S["bcur"]):
             e(s)
         for i in range(NI):
-            e(a_read(i))
+            for s in a_read(i, 0):
+                e(s)
         for q in range(NQ):
             for s in b_reads(q, 1, w):
                 e(s)
@@ -298,16 +342,17 @@ def kloop():
         e(f"s_cmp_lt_u32 s{S['t']}, s{S['tend']}")
         e(f"s_cbranch_scc1 L_fr_loop{w}_%=")
         e(f"L_fr_tail{w}_%=:")
-        e("s_cmp_eq_u32 %[hasnext], 0")
-        e(f"s_cbranch_scc1 L_fr_nonext{w}_%=")
-        # steps nk - 2, nk - 1 with a next tile: A (nk), A (nk + 1) are its stages 0, 1; B runs on cyclically
-        e(f"s_mov_b64 s[{S['pa']}:{S['pa'] + 1}], %[anext]")
-        for s in derive_pa1():
-            e(s)
-        step(e, w, "mid", True, True, 8, 12)
-        step(e, w, "last", True, True, 8, 12)
-        e("s_branch L_fr_done_%=")
-        e(f"L_fr_nonext{w}_%=:")
+        if not KMA:
+            e("s_cmp_eq_u32 %[hasnext], 0")
+            e(f"s_cbranch_scc1 L_fr_nonext{w}_%=")
+            # steps nk - 2, nk - 1 with a next tile: A (nk), A (nk + 1) are its stages 0, 1; B runs on cyclically
+            e(f"s_mov_b64 s[{S['pa']}:{S['pa'] + 1}], %[anext]")
+            for s in derive_pa1():
+                e(s)
+            step(e, w, "mid", True, True, 8, 12)
+            step(e, w, "last", True, True, 8, 12)
+            e("s_branch L_fr_done_%=")
+            e(f"L_fr_nonext{w}_%=:")
         # without one: step nk - 2 requests B (nk) (its first half is the tile's last k-half) and no A; step nk - 1 requests nothing
         step(e, w, "mid", True, False, 8, 12)     # even barrier: B (nk - 1) landed, A (nk - 1) may fly; odd: A (nk - 1) landed, B (nk) may fly
         step(e, w, "last", False, False, 0, 0)    # even barrier: B (nk) landed (nothing is newer)
@@ -336,20 +381,28 @@ def main(out):
         f.write("// The K loop of the full-row 256x384x64 GEMM as one inline-asm statement; operands and register plan: the generator's docstring.\n")
         total = 0
         global PAIRED
-        for stamped, paired in ((False, True), (False, False), (True, True), (True, False)):
-            STAMP, PAIRED = stamped, paired
-            name = "DEVIT_GEMMFR_KLOOP_" + ("PAIRED" if paired else "NATURAL") + ("_STAMPED" if stamped else "")
+        global KMA, TB
+        for stamped, paired, kma in ((False, True, False), (False, False, False), (True, True, False), (True, False, False),
+                                     (False, True, True), (True, True, True)):
+            STAMP, PAIRED, KMA, TB = stamped, paired, kma, (4 if kma else 2)
+            name = ("DEVIT_WGRADFR_KLOOP" if kma else "DEVIT_GEMMFR_KLOOP_" + ("PAIRED" if paired else "NATURAL")) + ("_STAMPED" if stamped else "")
             lines = kloop()
             n_mfma = sum(1 for s in lines if s.startswith("v_mfma"))
-            assert n_mfma == 4 * 6 * 2 * NM, n_mfma
+            assert n_mfma == 4 * (4 if kma else 6) * 2 * NM, n_mfma
+            if kma:
+                n_dot = sum(1 for s in lines if s.startswith("v_dot2c"))
+                assert n_dot == 4 * 4 * 2 * 16, n_dot
             total += len(lines)
             if stamped:
                 f.write("// diagnostic variant (-DDEVIT_GEMMFR_STAMP): s_memtime deltas per phase and per barrier wait, operands [d1], [d2] in addition\n")
+            if kma and not stamped:
+                f.write("// the WEIGHT-GRADIENT variant (wgradfr_kernel): A k-major, PAIRED order on both sides, column sums of A, one tile per workgroup\n")
             f.write(f"#define {name}_ASM \\\n")
             for s in lines:
                 f.write(f'  "{s}\\n\\t" \\\n')
             f.write('  ""\n')
             f.write(f"#define {name}_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n\n")
+        KMA, TB = False, 2
         STAMP = False
         f.write("// accumulators of m-tiles I0, I0 + 1 and the four n-tiles of column group H < 2 (tile q = 4 H + j) out of a[0:255]\n")
         f.write("template <int H, int I0>\n__device__ __forceinline__ void gemmfr_read_acc(f32x4 (&acc)[2][4]) {\n")
