@@ -421,6 +421,18 @@ class VisionTransformer(nn.Module):
                                f"{pinned!r} (de_vit.check_geometry)")
         self._precision = value
 
+    def request_precision(self, value):
+        """What a CLI does with its --teacher-precision flag: set it where the model has a choice; a model whose kernel family is pinned
+        (the D = 192 names run on the exact-fp32 kernels only) keeps it and says so once -- `--teacher-model deit_tiny_*` must not die on a
+        flag whose only values are 16-bit types (advisor r05)."""
+        pinned = getattr(self, "_pinned_precision", None)
+        if pinned is not None and value != pinned:
+            import warnings
+            warnings.warn(f"{type(self).__name__} (embed_dim {self.embed_dim}) runs on the {pinned!r} kernels only: --teacher-precision {value} ignored")
+            return pinned
+        self.precision = value
+        return value
+
     def pin_precision(self, value):
         """Fix the kernel family this model runs on (narrow geometries: "f32")."""
         self._pinned_precision = None

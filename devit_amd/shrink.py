@@ -108,6 +108,10 @@ def compact(model, trainable=False):
                             serial=_serial[0] * 100 + len(report),
                             heads_compacted=heads,
                             neurons_idx=w["kept_neurons"].to(dev))
+        # the dense k-major copy of fc2's weight (de_vit._w16t, made by an earlier dense forward) is never read while the block runs compacted:
+        # dropped, so that FlatParams.refresh_kmajor() stops re-transposing it after every optimizer step (advisor r05); a dense forward after
+        # uncompact() makes it again
+        blk.mlp.fc2.__dict__.pop("_w16t", None)
         c = blk._compact
         if c["fc2_w16"].is_cuda and c["fc2_w16"].shape[0] == 384:      # fc2's forward on the full-row GEMM (csrc/gemm.hip): k-major copy
             c["fc2_w16t"] = torch.empty((c["fc2_w16"].shape[1], 384), dtype=c["fc2_w16"].dtype, device=dev)

@@ -58,7 +58,7 @@ def get_models(args, num_subs, sub_classes, num_classes):
         teacher.to(args.device).eval()
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
-        teacher.precision = args.teacher_precision
+        teacher.request_precision(args.teacher_precision)
     model = MultiViT(model=args.model, drop=args.drop, drop_path=args.drop_path, num_div=num_subs, num_classes_list=sub_classes)
     # sub_size from the constructed backbones (the reference reads a wrong 192 from its config table)
     ens_model = EnsMLP(model=args.model, num_class=num_classes, sub_size=model.backbones[0].embed_dim,

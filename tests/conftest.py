@@ -29,11 +29,14 @@ def golden():
 _MARGINS = []
 
 
-def chk(value, bar):
+def chk(value, bar, name=None):
+    """name: a stable key for rows that something else reads back (bench.parity_statement) -- line numbers move"""
     import inspect
     fr = inspect.stack()[1]
-    _MARGINS.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "line": fr.lineno,
-                     "value": float(value), "bar": float(bar)})
+    row = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "line": fr.lineno, "value": float(value), "bar": float(bar)}
+    if name is not None:
+        row["name"] = name
+    _MARGINS.append(row)
     return value < bar
 
 

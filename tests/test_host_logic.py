@@ -30,7 +30,10 @@ def test_registry_semantics():
         assert m.embed_dim == 192 and m.blocks[0].attn.num_heads == 3 and m.precision == "f32"
         with pytest.raises(Exception, match="pinned"):
             m.precision = "bf16"
+        with pytest.warns(UserWarning, match="ignored"):          # what the CLIs do with --teacher-precision (default bf16) on such a teacher
+            assert m.request_precision("bf16") == "f32" and m.precision == "f32"
     assert registry.create_model("dedeit", num_classes=10).precision == "bf16"
+    assert registry.create_model("dedeit", num_classes=10).request_precision("f16") == "f16"
     assert registry.create_model("dedeit", embed_dim=320, num_heads=5, num_classes=10).precision == "f32"      # (5 heads x 64: narrow, fp32 kernels)
     with pytest.raises(NotImplementedError, match="multiples of 64"):
         registry.create_model("dedeit", embed_dim=320, num_heads=4)                                            # heads are not 64 wide

@@ -67,7 +67,7 @@ def main(args):
         teacher.to(device).eval()
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
-        teacher.precision = args.teacher_precision
+        teacher.request_precision(args.teacher_precision)
         if mixup_fn is not None:
             mixup_fn.set_precisions(model.precision, teacher.precision)
 
