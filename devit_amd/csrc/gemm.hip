@@ -168,17 +168,6 @@ __device__ __forceinline__ void dma2_perlane(const void* p0, const void* p1, uns
       : "memory", "scc");
 }
 
-template <bool NT = false>
-__device__ __forceinline__ void dma1_uniform(const char* ubase, unsigned off0, unsigned lds) {   // one slab (the odd one of seven)
-  unsigned keep;
-  if (NT)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %3, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds), "s"(ubase), "v"(off0) : "memory", "scc");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %3, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds), "s"(ubase), "v"(off0) : "memory", "scc");
-}
-
 // only_pair >= 0: issue just that pair of this wave's slabs (the ping-pong schedule spreads a stage's DMA instructions
 // over its barrier intervals)
 template <bool KM, int W, int NWAVES, bool NT = false>
@@ -318,7 +307,7 @@ __device__ __forceinline__ void settle_cols(f32x4 (&bias)[4], f32x4 (&cs)[4]) {
 template <int KIND, int MI, bool FULL, bool F16>
 __device__ __forceinline__ void epilogue_f32_rows(const devit_epilogue& ep, f32x4 (&acc)[MI][4], const int (&noff)[4],
                                                   const f32x4 (&bias)[4], int lane, int mw, int m_lim, size_t ob) {
-  constexpr int CHI = MI >= 2 ? 2 : 1;
+  constexpr int CHI = 2;
   const int c = lane & 15;
   const bool hi = c >= 8;
   const int colx = hi ? 16 : 0;                     // floats: second half of the line
@@ -397,7 +386,7 @@ __device__ __forceinline__ void epilogue_direct(const devit_epilogue& ep, f32x4 
     epilogue_f32_rows<KIND, MI, FULL, F16>(ep, acc, noff, bias, lane, mw, m_lim, ob);
     return;
   }
-  constexpr int CHI = MI >= 2 ? 2 : 1;
+  constexpr int CHI = 2;
   const int c = lane & 15;
 #pragma unroll
   for (int i0 = 0; i0 < MI; i0 += CHI) {
@@ -1178,18 +1167,14 @@ __device__ __forceinline__ int fr_b_row(int u, int wave, int K) {
   return r < 0 ? r + K : (r >= K ? r - K : r);
 }
 
-// BM = 256 (eight m-tiles per wave) or 224 (seven: the _M7 loops): 50688 rows are 198 tiles of 256 -- 58 of 256 CUs idle -- but 227 of 224, ONE
-// round with 84 instead of 96 MFMAs per phase and wave; the 224-row launch runs one tile per workgroup (the host selects it only then: the
-// last tile's rows past M are clamped in the per-lane request offsets, which a workgroup's NEXT tile would share).
-template <int KIND, int BM>
+template <int KIND>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemmfr_kernel(const GemmArgs g) {
   static_assert(KIND == DEVIT_EPI_RESIDUAL_F32 || KIND == DEVIT_EPI_STORE_BF16, "the student's N = 384 launches");
-  static_assert(BM == 256 || BM == 224, "eight or seven m-tiles per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BN = 384, NWAVES = 4, WM = BM / 2, MT = BM / 32;   // MT m-tiles per wave = 8-row slabs per wave and A stage
+  constexpr int BM = 256, BN = 384, NWAVES = 4;
   constexpr bool PAIRED = KIND == DEVIT_EPI_STORE_BF16;   // column order of the n-tiles, tile_row<PAIRED>()
-  constexpr int A_SLOT = 256 * BK * 2, B_SLOT = BN * BK * 2, B_RING = 2 * A_SLOT;     // (the A slots keep their 32 KB spacing at BM = 224)
+  constexpr int A_SLOT = BM * BK * 2, B_SLOT = BN * BK * 2, B_RING = 2 * A_SLOT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -1210,22 +1195,13 @@ void gemmfr_kernel(const GemmArgs g) {
 
   const unsigned lda64 = (unsigned)g.lda * 64u, ldbs = (unsigned)g.ldb * 128u, kb = (unsigned)g.K * (unsigned)g.ldb * 2u;
   const unsigned lds_base = (unsigned)(size_t)LDS_PTR(smem);
-  const unsigned wldsa = lds_base + (unsigned)wave * (MT * 1024u), wldsb = lds_base + (unsigned)wave * 12288u;   // (+ the slot's offset)
+  const unsigned wldsa = lds_base + (unsigned)wave * 8192u, wldsb = lds_base + (unsigned)wave * 12288u;   // (+ the slot's offset)
 
   // prologue: A stages 0, 1 of the first tile; B stages 0, 1 of the cyclic stream (one n-tile: every tile multiplies by the same B)
   TileRef ct = decode_tile<BM, BN, false, true>(g, first);
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    {   // A: this wave's MT slabs of 8 rows (rows past M: the last existing one, their products are never stored)
-      const int va = min(BM, g.M - ct.m0);
-      const char* ua = (const char*)(ct.a + (size_t)(ct.kt0 + st) * BK);
-      const unsigned la = lds_base + (unsigned)(st * A_SLOT) + (unsigned)wave * (MT * 1024u);
-#pragma unroll
-      for (int i = 0; i + 1 < MT; i += 2)
-        dma2_uniform<true>(ua, lane_offset<false, BM, NWAVES>(g.lda, wave, lane, i, va), lane_offset<false, BM, NWAVES>(g.lda, wave, lane, i + 1, va),
-                           la + i * 1024u);
-      if constexpr (MT % 2) dma1_uniform<true>(ua, lane_offset<false, BM, NWAVES>(g.lda, wave, lane, MT - 1, va), la + (MT - 1) * 1024u);
-    }
+    stage_tile<false, BM, NWAVES, true>(ct.a, g.lda, (ct.kt0 + st) * BK, 0, 0, smem + st * A_SLOT, wave, lane);
     const char* ub = (const char*)(ct.b + (size_t)fr_b_row(st, wave, g.K) * g.ldb);
     const unsigned lds0 = lds_base + (unsigned)(B_RING + st * B_SLOT) + (unsigned)wave * 12288u;
 #pragma unroll
@@ -1260,7 +1236,7 @@ void gemmfr_kernel(const GemmArgs g) {
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
-          const int rowA = wm * WM + 16 * par + c;
+          const int rowA = wm * 128 + 16 * par + c;
           dsA[kk * 2 + par] = (unsigned)(rowA * 128 + (((kk * 4 + gq) ^ swz_row(rowA)) * 16));
         }
       // read_frag<true, 384, PAIRED>: see b_reads() in tools/gen_gemmfr.py
@@ -1281,7 +1257,7 @@ void gemmfr_kernel(const GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) dsB[i] += lds_base;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dmaA[i] = lane_offset<false, BM, NWAVES>(g.lda, wave, lane_k, i, min(BM, g.M - ct.m0));
+      for (int i = 0; i < 4; ++i) dmaA[i] = lane_offset<false, BM, NWAVES>(g.lda, wave, lane_k, i, BM);
 #pragma unroll
       for (int i = 0; i < 12; ++i) dmaB[i] = fr_dma_off_b(g.ldb, wave, lane_k, i);
     }
@@ -1314,10 +1290,8 @@ void gemmfr_kernel(const GemmArgs g) {
                    [dmab4] "v"(dmaB[4]), [dmab5] "v"(dmaB[5]), [dmab6] "v"(dmaB[6]), [dmab7] "v"(dmaB[7]),                      \
                    [dmab8] "v"(dmaB[8]), [dmab9] "v"(dmaB[9]), [dmab10] "v"(dmaB[10]), [dmab11] "v"(dmaB[11])                   \
                  : DEVIT_FR_CLOB(O))
-    if constexpr (PAIRED && BM == 256) DEVIT_FR_STATEMENT(PAIRED);
-    else if constexpr (BM == 256) DEVIT_FR_STATEMENT(NATURAL);
-    else if constexpr (PAIRED) DEVIT_FR_STATEMENT(PAIRED_M7);
-    else DEVIT_FR_STATEMENT(NATURAL_M7);
+    if constexpr (PAIRED) DEVIT_FR_STATEMENT(PAIRED);
+    else DEVIT_FR_STATEMENT(NATURAL);
 #undef DEVIT_FR_STATEMENT
 #undef DEVIT_FR_STAMP_OUT
 #undef DEVIT_FR_ASM
@@ -1334,22 +1308,10 @@ void gemmfr_kernel(const GemmArgs g) {
     const int m_lim = ep.m_valid > 0 ? ep.m_valid : g.M;
     const bool full = ct.m0 + BM <= m_lim;
     f32x4 cs[4];   // (no column scale in these kinds)
-    // (BM = 224: the wave has seven m-tiles -- the chunk at i0 = 6 is ONE m-tile; the registers of an eighth hold nothing)
-    auto run = [&](auto mic, auto& acc, const int (&noff)[4], const f32x4 (&bias)[4], int i0) {
-      constexpr int MI = decltype(mic)::value;
-      const int mw = ct.m0 + wm * WM + i0 * 16;
-      if (full) epilogue_direct<KIND, MI, true, false>(ep, acc, noff, bias, cs, lane_e, mw, m_lim, ob);
-      else epilogue_direct<KIND, MI, false, false>(ep, acc, noff, bias, cs, lane_e, mw, m_lim, ob);
-    };
-    auto run_chunk = [&](f32x4 (&acc)[2][4], const int (&noff)[4], const f32x4 (&bias)[4], int i0) {
-      if (BM == 256 || i0 < 6) {
-        run(std::integral_constant<int, 2>(), acc, noff, bias, i0);
-      } else {
-        f32x4 one[1][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) one[0][j] = acc[0][j];
-        run(std::integral_constant<int, 1>(), one, noff, bias, i0);
-      }
+    auto run = [&](f32x4 (&acc)[2][4], const int (&noff)[4], const f32x4 (&bias)[4], int i0) {
+      const int mw = ct.m0 + wm * 128 + i0 * 16;
+      if (full) epilogue_direct<KIND, 2, true, false>(ep, acc, noff, bias, cs, lane_e, mw, m_lim, ob);
+      else epilogue_direct<KIND, 2, false, false>(ep, acc, noff, bias, cs, lane_e, mw, m_lim, ob);
     };
     {
       int noff[4];
@@ -1362,7 +1324,7 @@ void gemmfr_kernel(const GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[u][j] = (f32x4){c[16 * u + 4 * j], c[16 * u + 4 * j + 1], c[16 * u + 4 * j + 2], c[16 * u + 4 * j + 3]};
-        run_chunk(acc, noff, bias, i0);
+        run(acc, noff, bias, i0);
       };
       from_v(c0, 0);
       from_v(c1, 2);
@@ -1378,7 +1340,7 @@ void gemmfr_kernel(const GemmArgs g) {
         constexpr int I0 = decltype(ic)::value;
         f32x4 acc[2][4];
         gemmfr_read_acc<H, I0>(acc);
-        run_chunk(acc, noff, bias, I0);
+        run(acc, noff, bias, I0);
       };
       chunk(std::integral_constant<int, 0>());
       chunk(std::integral_constant<int, 2>());
@@ -1631,16 +1593,6 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // CUs the persistent grids leave free (devit_set_reserved_cus): -1 = not set yet, take DEVIT_RESERVE_CUS from the environment
 int g_reserved_cus = -1;
 
-// CUs of the current device (0 if it cannot be asked); asked once
-int cached_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = n;
-  }
-  return cus;
-}
-
 int reserved_cus() {
   if (g_reserved_cus < 0) {
     const char* e = getenv("DEVIT_RESERVE_CUS");
@@ -1813,18 +1765,8 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
               "M %% 256 == 0, >= 64 row tiles, K >= 192, DEVIT_GEMMFR != 0, no row_group / row_skip on B): M=%d N=%d K=%d row_group=%d", M, N, K,
               Bop->row_group);
   if (use_fr) cfg = 4;
-  // the full-row launch on 224-row tiles when that is ONE round of one tile per workgroup (M = 50688: 227 tiles; on 256-row tiles 198 of 256 CUs
-  // work and 58 idle): fewer CUs than tiles (a CU reservation, a larger batch) keep the 256-row tile, whose workgroups walk several tiles.
-  // DEVIT_GEMMFR_BM=256 forces it (read per call: tests and A/Bs switch it).
-  bool fr224 = false;
-  if (cfg == 4) {
-    const char* e = getenv("DEVIT_GEMMFR_BM");
-    const int want = (e && *e) ? atoi(e) : 224;
-    const int avail_cus = cached_cu_count() - reserved_cus();
-    fr224 = want == 224 && (M + 223) / 224 <= avail_cus / 8 * 8 && M / 256 >= 64 && (M + 223) / 224 > M / 256;
-  }
-  const int bm = cfg == 1 ? 128 : (fr224 ? 224 : 256), bn = cfg == 4 ? 384 : bm;
-  g.tiles_m = (M + bm - 1) / bm;
+  const int bm = cfg == 1 ? 128 : 256, bn = cfg == 4 ? 384 : bm;
+  g.tiles_m = M / bm;
   g.tiles_n = (N + bn - 1) / bn;
   {
     // Tile order inside an XCD: n-tile fastest inside chunks of gn n-tiles, so that the W workgroups an XCD runs at
@@ -1851,8 +1793,14 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
   g.d_split = make_fastdiv(split_k);
   // persistent grid: as many workgroups as stay resident (LDS: two 128x128 rings or one 256-wide ring per CU), a
   // multiple of 8 so that every XCD gets the same number
-  const int cus = cached_cu_count();
-  DEVIT_CHECK(cus >= 8, DEVIT_ERR_DEVICE, "devit_gemm_bf16: cannot query the CU count");
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    DEVIT_CHECK(hipGetDevice(&dev) == hipSuccess &&
+                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8,
+                DEVIT_ERR_DEVICE, "devit_gemm_bf16: cannot query the CU count");
+    cus = n;
+  }
   static const int occ_env = getenv("DEVIT_GEMM_OCC") ? atoi(getenv("DEVIT_GEMM_OCC")) : 0;
   const int occ = cfg == 4 ? 1 : occ_env > 0 ? occ_env : (cfg == 1 ? 2 : 1);
   // A persistent grid holds every CU it starts on (the 256x256 workgroup owns the CU's whole LDS and register file) until
@@ -1937,23 +1885,21 @@ extern "C" int devit_gemm_bf16(const devit_operand* Aop, const devit_operand* Bo
     }                                                                                                          \
     hipLaunchKernelGGL((gemm4_kernel<KIND_, false>), dim3((unsigned)nwg), dim3(256), lds, s, g);               \
   } while (0)
-#define DEVIT_LAUNCH_GEMMFR(KIND_, BM_)                                                                         \
+#define DEVIT_LAUNCH_GEMMFR(KIND_)                                                                              \
   do {                                                                                                         \
     constexpr int lds = (256 + 384) * 128 * 2;                                                                 \
     static bool attr = false;                                                                                  \
     if (!attr) {                                                                                               \
-      hipError_t e = hipFuncSetAttribute((const void*)gemmfr_kernel<KIND_, BM_>,                               \
+      hipError_t e = hipFuncSetAttribute((const void*)gemmfr_kernel<KIND_>,                                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
       DEVIT_CHECK(e == hipSuccess, DEVIT_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
       attr = true;                                                                                             \
     }                                                                                                          \
-    hipLaunchKernelGGL((gemmfr_kernel<KIND_, BM_>), dim3((unsigned)nwg), dim3(256), lds, s, g);                \
+    hipLaunchKernelGGL((gemmfr_kernel<KIND_>), dim3((unsigned)nwg), dim3(256), lds, s, g);                     \
   } while (0)
   if (cfg == 4) {
-    if (ep->kind == DEVIT_EPI_STORE_BF16 && fr224) DEVIT_LAUNCH_GEMMFR(DEVIT_EPI_STORE_BF16, 224);
-    else if (ep->kind == DEVIT_EPI_STORE_BF16) DEVIT_LAUNCH_GEMMFR(DEVIT_EPI_STORE_BF16, 256);
-    else if (fr224) DEVIT_LAUNCH_GEMMFR(DEVIT_EPI_RESIDUAL_F32, 224);
-    else DEVIT_LAUNCH_GEMMFR(DEVIT_EPI_RESIDUAL_F32, 256);
+    if (ep->kind == DEVIT_EPI_STORE_BF16) DEVIT_LAUNCH_GEMMFR(DEVIT_EPI_STORE_BF16);
+    else DEVIT_LAUNCH_GEMMFR(DEVIT_EPI_RESIDUAL_F32);
   } else if (use4) {
     switch (ep->kind) {
       case DEVIT_EPI_STORE_BF16: DEVIT_LAUNCH_GEMM4(DEVIT_EPI_STORE_BF16); break;

@@ -37,9 +37,6 @@ columns 192 wn.. of the tile: 8 m-tiles x 12 n-tiles of 16 x 16):
   * the request stream runs across tile boundaries: A (nk), A (nk + 1) = stages 0, 1 of the workgroup's NEXT tile ([anext]; only with
     [hasnext]), B is the same cyclic stream for every tile (N = 384: one n-tile).
   * at entry the statement reads the fragments of phase 0 itself; at exit the accumulators stay in a[0:255] / [c0]..[c3].
-  * the 224-ROW tile (round 6, _M7 variants; NI = 7): M = 50688 rows are 198 tiles of 256 -- 58 of 256 CUs idle in every launch -- but 227 tiles
-    of 224 (one round, 84 instead of 96 MFMAs per phase and wave).  Seven m-tiles per wave (rows 112 wm ..: the accumulator plan above with
-    i < 7), seven 8-row slabs = seven A requests per wave and stage (rows 56 w ..), everything else as above.
 
 Operands of the asm statement (named; declared in gemmfr_kernel):
   [c0]..[c3] =&{v[128:159]} ... f32x32   [acur] +s LDS byte offset of the A slot of this tile's stage 0 (0 / 32768)
@@ -76,7 +73,7 @@ import sys
 A_SLOT = 32768
 B_BASE = 2 * A_SLOT
 B_SLOT = 49152
-NI, NQ = 8, 12              # m-tiles, n-tiles per wave (NI = 7: the 224-row tile, see main())
+NI, NQ = 8, 12              # m-tiles, n-tiles per wave
 NM = NI * NQ                # MFMAs per phase
 FA, FB, VACC = 48, 80, 128  # first registers of the A / B fragments and of the VGPR-resident accumulators
 BAR_GAP = NQ - 1            # a phase's barrier sits behind MFMA (0, 11)
@@ -152,7 +149,7 @@ def requests_a():
     if KMA:
         return [(f"s_add_u32 m0, s{S['dstA']}, {i * 1024}", f"global_load_lds_dwordx4 %[dmaa{i}], s[{S['pa']}:{S['pa'] + 1}]" + (" nt" if A_NT else ""))
                 for i in range(8)]
-    for i in range(NI):     # one 8-row slab per m-tile of the wave's two row halves: BM / 32 = NI slabs per wave
+    for i in range(8):
         base = S["pa"] if i < 4 else S["pa1"]
         out.append((f"s_add_u32 m0, s{S['dstA']}, {i * 1024}", f"global_load_lds_dwordx4 %[dmaa{i & 3}], s[{base}:{base + 1}]" + (" nt" if A_NT else "")))
     return out
@@ -286,7 +283,6 @@ def step(e, wave, kind, req_b, req_a, vm_even, vm_odd):
 def kloop():
     e_lines = []
     e = e_lines.append
-    NA = 8 if KMA else NI       # requests per wave and A stage = what an even barrier's counted vmcnt leaves in flight
     e(f"s_mov_b32 s{S['m0save']}, m0")
     if STAMP:
         e(f"s_mov_b32 s{ST['d1']}, 0")
@@ -341,7 +337,7 @@ def kloop():
         e(f"s_cmp_lt_u32 s{S['t']}, s{S['tend']}")
         e(f"s_cbranch_scc0 L_fr_tail{w}_%=")
         e(f"L_fr_loop{w}_%=:")
-        step(e, w, "mid", True, True, NA, 12)
+        step(e, w, "mid", True, True, 8, 12)
         e(f"s_add_u32 s{S['t']}, s{S['t']}, 1")
         e(f"s_cmp_lt_u32 s{S['t']}, s{S['tend']}")
         e(f"s_cbranch_scc1 L_fr_loop{w}_%=")
@@ -353,12 +349,12 @@ def kloop():
             e(f"s_mov_b64 s[{S['pa']}:{S['pa'] + 1}], %[anext]")
             for s in derive_pa1():
                 e(s)
-            step(e, w, "mid", True, True, NA, 12)
-            step(e, w, "last", True, True, NA, 12)
+            step(e, w, "mid", True, True, 8, 12)
+            step(e, w, "last", True, True, 8, 12)
             e("s_branch L_fr_done_%=")
             e(f"L_fr_nonext{w}_%=:")
         # without one: step nk - 2 requests B (nk) (its first half is the tile's last k-half) and no A; step nk - 1 requests nothing
-        step(e, w, "mid", True, False, NA, 12)     # even barrier: B (nk - 1) landed, A (nk - 1) may fly; odd: A (nk - 1) landed, B (nk) may fly
+        step(e, w, "mid", True, False, 8, 12)     # even barrier: B (nk - 1) landed, A (nk - 1) may fly; odd: A (nk - 1) landed, B (nk) may fly
         step(e, w, "last", False, False, 0, 0)    # even barrier: B (nk) landed (nothing is newer)
         if w < 3:
             e("s_branch L_fr_done_%=")
@@ -385,13 +381,11 @@ def main(out):
         f.write("// The K loop of the full-row 256x384x64 GEMM as one inline-asm statement; operands and register plan: the generator's docstring.\n")
         total = 0
         global PAIRED
-        global KMA, TB, NI, NM
-        for stamped, paired, kma, ni in ((False, True, False, 8), (False, False, False, 8), (True, True, False, 8), (True, False, False, 8),
-                                         (False, True, True, 8), (True, True, True, 8),
-                                         (False, True, False, 7), (False, False, False, 7), (True, True, False, 7), (True, False, False, 7)):
-            STAMP, PAIRED, KMA, TB, NI, NM = stamped, paired, kma, (4 if kma else 2), ni, ni * NQ
-            name = ("DEVIT_WGRADFR_KLOOP" if kma else "DEVIT_GEMMFR_KLOOP_" + ("PAIRED" if paired else "NATURAL")) + ("_M7" if ni == 7 else "") + \
-                   ("_STAMPED" if stamped else "")
+        global KMA, TB
+        for stamped, paired, kma in ((False, True, False), (False, False, False), (True, True, False), (True, False, False),
+                                     (False, True, True), (True, True, True)):
+            STAMP, PAIRED, KMA, TB = stamped, paired, kma, (4 if kma else 2)
+            name = ("DEVIT_WGRADFR_KLOOP" if kma else "DEVIT_GEMMFR_KLOOP_" + ("PAIRED" if paired else "NATURAL")) + ("_STAMPED" if stamped else "")
             lines = kloop()
             n_mfma = sum(1 for s in lines if s.startswith("v_mfma"))
             assert n_mfma == 4 * (4 if kma else 6) * 2 * NM, n_mfma
@@ -403,14 +397,11 @@ def main(out):
                 f.write("// diagnostic variant (-DDEVIT_GEMMFR_STAMP): s_memtime deltas per phase and per barrier wait, operands [d1], [d2] in addition\n")
             if kma and not stamped:
                 f.write("// the WEIGHT-GRADIENT variant (wgradfr_kernel): A k-major, PAIRED order on both sides, column sums of A, one tile per workgroup\n")
-            if ni == 7 and not stamped and paired:
-                f.write("// the 224-ROW tile (_M7): seven m-tiles per wave (rows 112 wm ..), seven A requests per wave and stage; 50688 rows = 227 tiles = one round on 256 CUs\n")
             f.write(f"#define {name}_ASM \\\n")
             for s in lines:
                 f.write(f'  "{s}\\n\\t" \\\n')
             f.write('  ""\n')
             f.write(f"#define {name}_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n\n")
-        NI, NM = 8, 8 * NQ
         KMA, TB = False, 2
         STAMP = False
         f.write("// accumulators of m-tiles I0, I0 + 1 and the four n-tiles of column group H < 2 (tile q = 4 H + j) out of a[0:255]\n")
