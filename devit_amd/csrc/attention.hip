@@ -403,13 +403,22 @@ __global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnB
   for (int t = 0; t < B4_KT; ++t) {
     const int key = min((wave + t * B4_WAVES) * 16 + lc, N - 1);
 #pragma unroll
+#ifdef DEVIT_ATTN_ABL_NOV       // ablation build (round 6): no V loads
+    for (int kk = 0; kk < 2; ++kk) asm volatile("" : "=v"(vf[t][kk]));
+#else
     for (int kk = 0; kk < 2; ++kk) vf[t][kk] = *(const bf16x8*)(vbase + (size_t)key * krs + kk * 32 + g * 8);
+#endif
   }
   {
     constexpr int NT = B4_WAVES * 64;
     RowRegs<NT> dr, orr;
+#ifdef DEVIT_ATTN_ABL_NODELTA   // ablation build (round 6): no dO / O rows for delta
+#pragma unroll
+    for (int it = 0; it < RowRegs<NT>::ITERS; ++it) { asm volatile("" : "=v"(dr.v[it])); asm volatile("" : "=v"(orr.v[it])); }
+#else
     fetch_rows(dr, dobase, (size_t)D, NQ, tid);
     fetch_rows(orr, obase, (size_t)D, NQ, tid);
+#endif
     ATTN_STAMP(6);                                     // every prologue load is issued
 #ifdef DEVIT_ATTN_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -446,7 +455,11 @@ __global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnB
       dk[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
+#ifdef DEVIT_ATTN_ABL_NOMAIN    // ablation build (round 6): prologue + final stores only
+  for (int qb = 0; qb < (a.N < 0 ? nblk : 0); ++qb) {
+#else
   for (int qb = 0; qb < nblk; ++qb) {
+#endif
     const char* q_blk = qd + (qb & (QD_NST - 1)) * QD_STAGE;
     const char* do_blk = q_blk + 32 * HD * 2;
     // Q / dO of block qb + 3 into the stage block qb - 1 was read from (every wave is past that block's barriers).  Exactly

@@ -325,7 +325,14 @@ extern "C" int devit_block_bwd(const devit_block_weights* wp, const devit_block_
     nj = 0;
     return devit_wgrad_grouped(jobs, n, c.Mp, 0, cs.stream);
   };
-  TRY(wgrad(0, io->g2, b[DEVIT_ACT_H], g.fc2_w, io->g2_bias_done ? nullptr : g.fc2_b, D, Hd));
+  // fc2's product is taken transposed (its 384 outputs are the B side): its bias gradient cannot come out of the grouped kernel.  Every block but the
+  // topmost got it from the LN1 backward of the block above; the topmost takes a column-sum pass over g2 (the LayerNorm workspace is idle here).
+  bool fc2_bias_here = !io->g2_bias_done;
+  if (fc2_bias_here && wmode && Hd % 128 == 0 && io->lnws_bytes >= devit_colsum_workspace(c.Mp, D)) {
+    TRY(devit_colsum_bf16(io->g2, c.Mp, D, D, 0, 0, g.fc2_b, 1, io->ws[DEVIT_BWD_LNWS], io->lnws_bytes, stream));
+    fc2_bias_here = false;
+  }
+  TRY(wgrad(0, io->g2, b[DEVIT_ACT_H], g.fc2_w, fc2_bias_here ? g.fc2_b : nullptr, D, Hd));
   {
     devit_epilogue ep = make_ep(DEVIT_EPI_DGELU_BF16, dh_pre, Hd, c.M);
     ep.colscale = w.neuron_gate;

@@ -323,7 +323,7 @@ class DeferredWgrads:
 
     def last_of_group(self, i):
         """Is block i the last (lowest) block of its group?  (backward walks i downwards)"""
-        if i == 0 or self.policy == "block" or len(self.jobs) + 8 > L.WGRAD_MAX_JOBS:
+        if i == 0 or self.policy == "block" or len(self.jobs) + 4 > L.WGRAD_MAX_JOBS:   # (no room for the next block's four)
             return True
         return self.policy == "bucket" and self.bucket[i] != self.bucket[i - 1]
 
@@ -486,7 +486,11 @@ def _block_backward(dx, g2, s, bp, cfg, dqkv_add, datt, prev_dp2, want_prev_g, p
         else:
             js.append(j)
             keep.extend((dy, x, w_grad, b_grad))
-    wgrad(g2, s["h"], grad_buf(bp.fc2_w), None if g2_bias_done else grad_buf(bp.fc2_b))
+    fc2_bias = None if g2_bias_done else grad_buf(bp.fc2_b)
+    if fc2_bias is not None and defer is not None and wgrad_enabled(pad_rows(M)) and D == 384 and Hd % 128 == 0:
+        colsum(g2, pad_rows(M), D, fc2_bias, True)      # (the transposed product has no bias-gradient side: devit_block_bwd does the same)
+        fc2_bias = None
+    wgrad(g2, s["h"], grad_buf(bp.fc2_w), fc2_bias)
     dh_pre = rows_alloc(M, Hd, BF16, dev)
     linear_dgrad(g2, bp.fc2_w16, M, out=dh_pre, kind=L.EPI_DGELU_BF16, colscale=bp.neuron_gate, aux_in=s["h_pre"],
                  exact_gelu=cfg.exact_gelu)
@@ -606,7 +610,7 @@ def _tail_forward(x, bp, dp, cfg, need_grad, ntok):
     return x2o, s
 
 
-def _tail_backward(dx, s, bp, cfg):
+def _tail_backward(dx, s, bp, cfg, defer=None):
     """dx: fp32 [B, ntok, D] gradient of _tail_forward's output.  Returns the fp32 [B, N, D] gradient of its input.
     Every product that the full block's backward forms from the 196 untouched rows per image is an exact zero there (their
     output gradient is zero), so the sums here hold the same terms; the token rows of dln1 are produced by one K = 3D GEMM
@@ -647,8 +651,14 @@ def _tail_backward(dx, s, bp, cfg):
     linear_dgrad(dqkv_tok, bp.qkv_w16, T, out=dln1_tok)
     dln1[:M].view(B, N, D)[:, :ntok].copy_(dln1_tok[:T].view(B, ntok, D))
     gw, gb = grad_buf(bp.qkv_w), grad_buf(bp.qkv_b)
-    linear_wgrad(dkv, s["ln1"], gw[Da:], gb[Da:], M)
+    # the one product of this block that reduces over ALL rows (dK | dV against ln1) can ride the encoder's grouped weight-gradient launch
+    # (defer: a DeferredWgrads whose single group is launched behind block 0 -- the caller then reports this block with that group)
+    j = wgrad_job_struct(dkv, s["ln1"], gw[Da:], gb[Da:]) if (defer is not None and wgrad_enabled(pad_rows(M))) else None
+    if j is None:
+        linear_wgrad(dkv, s["ln1"], gw[Da:], gb[Da:], M)
     linear_wgrad(dqkv_tok[:, :Da], s["ln1_tok"], gw[:Da], gb[:Da], T)
+    if defer is not None:
+        defer.add(bp, [j] if j is not None else [], (dkv, s["ln1"], gw, gb))
     dx0 = torch.empty((B, N, D), dtype=F32, device=dev)
     layernorm_bwd(dln1, False, x.view(M, D), M, D, s["mean1"], s["rstd1"], bp.n1w, None, dx0.view(M, D), None, None, 0,
                   grad_buf(bp.n1w), grad_buf(bp.n1b))
@@ -800,13 +810,12 @@ def _wgrads_struct(bp):
     return g
 
 
-def _encoder_backward_composite(run, cfg, dx, dqkvs):
+def _encoder_backward_composite(run, cfg, dx, dqkvs, defer):
     """dx: fp32 [B,N,D] contiguous gradient of the encoder output.  Returns the gradient of the encoder input."""
     B, N, D = run.dims
     M, dev, nb = B * N, dx.device, run.nb
     mp = pad_rows(M)
     sz, offs, tot = _bwd_sizes(B, N, D, {(run.weights[i].attn_width, run.weights[i].hidden) for i in range(nb)})
-    defer = DeferredWgrads(cfg, nb)
     # Workspace: the transient buffers shared by all blocks + two fp32 dx buffers that alternate + per-block SLOTS for what a deferred
     # weight-gradient job reads (bf16 g2 = the branch gradient entering the block, dh_pre, g1, dqkv): they must outlive the block's call until
     # its group is launched.  Groups of one block need two slots (block i reads g of slot i, writes the next block's into the other one).
@@ -927,11 +936,17 @@ class EncoderFn(torch.autograd.Function):
             last = cfg.blocks[-1]
             if dx is None:
                 dx = torch.zeros_like(tail["x1"])
-            dx = _tail_backward(dx, tail, last, cfg)
-            last.finish_grads()
-            if cfg.grad_ready is not None:
-                cfg.grad_ready(last.all_params())
             nb -= 1
+            defer = DeferredWgrads(cfg, nb)
+            if defer.policy == "all":          # (no exchange to overlap: the last block is reported with the one group)
+                dx = _tail_backward(dx, tail, last, cfg, defer)
+            else:
+                dx = _tail_backward(dx, tail, last, cfg)
+                last.finish_grads()
+                if cfg.grad_ready is not None:
+                    cfg.grad_ready(last.all_params())
+        else:
+            defer = DeferredWgrads(cfg, nb)
         if ctx.run is not None:
             run = ctx.run
             if any(d is not None for d in datts) or any(d is not None for d in dencs):
@@ -940,7 +955,7 @@ class EncoderFn(torch.autograd.Function):
             B, N, D = run.dims
             if dx is None:
                 dx = torch.zeros((B, N, D), dtype=F32, device=run.x.device)
-            dx_in = _encoder_backward_composite(run, cfg, dx.contiguous(), dqkvs if nq else None)
+            dx_in = _encoder_backward_composite(run, cfg, dx.contiguous(), dqkvs if nq else None, defer)
             ctx.run = None
             return (dx_in, None) + (None,) * nparams
         B, N, D = saved[0]["x"].shape
@@ -951,7 +966,6 @@ class EncoderFn(torch.autograd.Function):
             dx = dx + dencs[nb - 1]
         g = scale_cast(dx, saved[nb - 1]["dp2"], N)
         g_bias_done = False           # fc2 bias gradient of block i comes fused from block i+1's LN1 backward
-        defer = DeferredWgrads(cfg, nb)
         for i in range(nb - 1, -1, -1):
             bp = cfg.blocks[i]
             dq = dqkvs[i] if nq else None
