@@ -327,11 +327,7 @@ __device__ __forceinline__ void store_grad4(__bf16* dst, const __bf16* add, f32x
 // the softmax-gradient arithmetic took it from 26 to 22) + stores 2.
 // ------------------------------------------------------------------------------------------
 constexpr int B4_WAVES = 4;
-#ifdef DEVIT_ATTN_B4_KT           // diagnostic builds only (timing of the main-loop variants on the wave's first key tiles: wrong results)
-constexpr int B4_KT = DEVIT_ATTN_B4_KT;
-#else
-constexpr int B4_KT = (MAXT + 1 + B4_WAVES - 1) / B4_WAVES;
-#endif      // key tiles per wave (4); tile 13 (keys 208..223) is padding
+constexpr int B4_KT = (MAXT + 1 + B4_WAVES - 1) / B4_WAVES;      // key tiles per wave (4); tile 13 (keys 208..223) is padding
 constexpr int DST4_STRIDE = 36;                                   // bf16 per dS^T row: 32 queries + pad (72-B rows)
 constexpr int DST4_BYTES = KROWS * DST4_STRIDE * 2;               // 16128
 constexpr int QD_STAGE = 2 * 32 * HD * 2;                         // one ring stage: Q block + dO block, 8192 B
@@ -473,74 +469,6 @@ __global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnB
       dma_block(nq, qbase, rs, (qb + QD_NST - 1) * 32, NQ, wave, lane);
       dma_block(nq + 32 * HD * 2, dobase, (size_t)D, (qb + QD_NST - 1) * 32, NQ, wave, lane);
     }
-#ifdef DEVIT_ATTN_TWO_PHASE      // diagnostic (round 6, NULLS 34): the two-phase block loop; fits the registers only with B4_KT = 3
-    bf16x8 pf[B4_KT], dsf[B4_KT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      asm volatile("" ::: "memory");
-      bf16x8 qf[2], df[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        qf[kk] = img_row_frag(q_blk, i * 16, kk, lane);
-        df[kk] = img_row_frag(do_blk, i * 16, kk, lane);
-      }
-      const f32x4 l2 = *(const f32x4*)(lse2 + qb * 32 + i * 16 + g * 4), dl = *(const f32x4*)(delta + qb * 32 + i * 16 + g * 4);
-      const bool qfull = qb * 32 + i * 16 + 16 <= NQ;
-#pragma unroll
-      for (int t = 0; t < B4_KT; ++t) {
-        const int kt = wave + t * B4_WAVES;
-        if (kt < ntile) {
-          f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            sv = mfma16(qf[kk], img_row_frag(k_img, kt * 16, kk, lane), sv);
-            dp = mfma16(df[kk], vf[t][kk], dp);
-          }
-          float pp[4], ds[4];
-          if (kt * 16 + 16 <= N && qfull) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -l2[r]));
-              pp[r] = p;
-              ds[r] = p * fmaf(dp[r], gs, -dl[r]);
-            }
-          } else {
-            const bool kok = kt * 16 + lc < N;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const bool ok = kok && (qb * 32 + i * 16 + g * 4 + r < NQ);
-              const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -l2[r])) : 0.f;
-              pp[r] = p;
-              ds[r] = p * fmaf(dp[r], gs, -dl[r]);
-            }
-          }
-          const bf16x4 dsb = {f2bf(ds[0]), f2bf(ds[1]), f2bf(ds[2]), f2bf(ds[3])};
-          const bf16x4 ppb = {f2bf(pp[0]), f2bf(pp[1]), f2bf(pp[2]), f2bf(pp[3])};
-          *(bf16x4*)(dst + (kt * 16 + lc) * (DST4_STRIDE * 2) + (i * 16 + g * 4) * 2) = dsb;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            pf[t][i * 4 + r] = ppb[r];
-            dsf[t][i * 4 + r] = dsb[r];
-          }
-        }
-      }
-    }
-    {
-      const int r0 = g * 4 + tq, r1 = r0 + 16;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int ch = dt * 2 + (tp >> 1), sub = (tp & 1) * 8;
-        const bf16x8 dot = cat8(lds_tr_read(do_blk + img_off(r0, ch) + sub), lds_tr_read(do_blk + img_off(r1, ch) + sub));
-        const bf16x8 qtt = cat8(lds_tr_read(q_blk + img_off(r0, ch) + sub), lds_tr_read(q_blk + img_off(r1, ch) + sub));
-#pragma unroll
-        for (int t = 0; t < B4_KT; ++t)
-          if (wave + t * B4_WAVES < ntile) {
-            dv[t][dt] = mfma16(dot, pf[t], dv[t][dt]);
-            dk[t][dt] = mfma16(qtt, dsf[t], dk[t][dt]);
-          }
-      }
-    }
-#else
     // ---- per key tile of this wave: S and dP against the block's two query tiles -> P, dS (registers = MFMA operands, dS^T also
     // to LDS), then dV^T += dO^T P and dK^T += Q^T dS.  The block's Q / dO fragments are read from LDS per tile, not held
     // across tiles: with 128 accumulator and 32 V-fragment registers there is no room for them (256 per wave at two
@@ -603,7 +531,6 @@ __global__ __launch_bounds__(B4_WAVES * 64, 2) void attn_bwd4_kernel(const AttnB
         }
       }
     }
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // Y1: dS^T of this block complete
     asm volatile("" ::: "memory");                      // (s_barrier is IntrNoMem: no LDS access may be moved across it)

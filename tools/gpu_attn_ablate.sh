@@ -1,7 +1,6 @@
 #!/bin/bash
-# attention backward variants (round 6): tools/_diag/libdevit_$v.so for every argument (default: the ablation set), two interleaved passes, cold
-VARS=${@:-anov anodelta anovd anomain}
+# attention backward ablations (round 6): default library vs tools/_diag/libdevit_a{nov,nodelta,novd,nomain}.so, two interleaved passes, cold
 for i in 1 2; do
   timeout 120 python tools/attn_ab.py
-  for v in $VARS; do DEVIT_LIB_PATH=$PWD/tools/_diag/libdevit_$v.so timeout 120 python tools/attn_ab.py; done
+  for v in anov anodelta anovd anomain; do DEVIT_LIB_PATH=$PWD/tools/_diag/libdevit_$v.so timeout 120 python tools/attn_ab.py; done
 done
