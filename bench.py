@@ -570,6 +570,7 @@ def main():
                        "shrink": shrink_info},
             "reserved_cus": reserved_cus, "reserved_cus_while_buckets_in_flight": reducer.reserve_cus if reducer.world > 1 else 0,
             "rehearse_exchange": args.rehearse_exchange,
+            "wgrad_groups": ops.DeferredWgrads(type("C", (), {"grad_ready": student.grad_ready, "blocks": []})(), 0).policy,   # all blocks in one launch / the reducer's buckets
             "bucket_mb": [round((e - s_) * 4 / 2 ** 20, 2) for s_, e, _, _ in reducer.buckets],
             "allreduce_ms": exchange["allreduce_ms"] if exchange else None,
             "overlap_frac": exchange["overlap_frac"] if exchange else None, "exchange": exchange,

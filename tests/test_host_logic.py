@@ -287,3 +287,66 @@ def test_bench_cites_the_profile_taken_on_the_current_kernel_sources(tmp_path, m
     v, src = bench.committed_counter("*_pmc_traffic.json", "traffic_bytes_per_launch")
     assert v is None and src["stale"] is True and src["file"].endswith("r99_w_pmc_traffic.json")
     assert bench.parity_statement()["stale"] is True
+
+
+def test_deferred_wgrad_groups(monkeypatch):
+    """ops.DeferredWgrads: which blocks' weight gradients share one launch of the grouped kernel.  Without a gradient exchange to overlap: all blocks of
+    the encoder call, launched behind block 0; with a reducer of world > 1 on grad_ready: the blocks of one bucket (so that every bucket still leaves as
+    soon as its gradients exist); DEVIT_WGRAD_GROUP forces either; a full job table flushes early."""
+    from devit_amd import ops, _lib as L
+
+    class BP:
+        def __init__(self, i):
+            self.i = i
+
+        def all_params(self):
+            return [self.i]
+
+        def finish_grads(self):
+            pass
+
+    class Hook:
+        world = 2
+
+        def __init__(self):
+            self.seen = []
+
+        def __call__(self, params):
+            self.seen += params
+
+        def bucket_of(self, params):
+            return {10: 0, 9: 1, 8: 1, 7: 1, 6: 2, 5: 2, 4: 2, 3: 3, 2: 3, 1: 4, 0: 5}[params[0]]
+
+    class Cfg:
+        pass
+    monkeypatch.delenv("DEVIT_WGRAD_GROUP", raising=False)
+    cfg = Cfg()
+    cfg.blocks = [BP(i) for i in range(11)]
+    cfg.grad_ready = Hook()
+    d = ops.DeferredWgrads(cfg, 11)
+    assert d.policy == "bucket"
+    assert [i for i in range(10, -1, -1) if d.last_of_group(i)] == [10, 7, 4, 2, 1, 0]
+    cfg.grad_ready.world = 1                                    # nothing to overlap: one group
+    d = ops.DeferredWgrads(cfg, 11)
+    assert d.policy == "all" and [i for i in range(10, -1, -1) if d.last_of_group(i)] == [0]
+    d.jobs = [None] * (L.WGRAD_MAX_JOBS - 3)                    # no room for another block's four products: launch what is there
+    assert d.last_of_group(5)
+    cfg.grad_ready = lambda params: None                        # a plain callback (no reducer): one group
+    assert ops.DeferredWgrads(cfg, 11).policy == "all"
+    monkeypatch.setenv("DEVIT_WGRAD_GROUP", "block")
+    d = ops.DeferredWgrads(cfg, 11)
+    assert all(d.last_of_group(i) for i in range(11))
+    monkeypatch.setenv("DEVIT_WGRAD_GROUP", "bucket")           # asked for, but no reducer to align with
+    assert ops.DeferredWgrads(cfg, 11).policy == "all"
+    monkeypatch.setenv("DEVIT_WGRAD_GROUP", "nonsense")
+    with pytest.raises(Exception, match="DEVIT_WGRAD_GROUP"):
+        ops.DeferredWgrads(cfg, 11)
+    # flush with nothing recorded reports the pending blocks and launches nothing (no GPU touched)
+    monkeypatch.setenv("DEVIT_WGRAD_GROUP", "all")
+    hook = Hook()
+    cfg.grad_ready = hook
+    d = ops.DeferredWgrads(cfg, 11)
+    d.add(cfg.blocks[3], [])
+    d.add(cfg.blocks[2], [])
+    d.flush(512)
+    assert hook.seen == [3, 2] and d.pending == []
