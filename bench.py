@@ -361,8 +361,13 @@ def main():
     # The frozen teacher runs one batch ahead on the side stream (engine.TeacherLookahead): every step still enqueues
     # exactly one teacher forward -- the one for the next batch -- beside its own student forward/backward.
     look = engine.TeacherLookahead(teacher) if args.teacher_lookahead else None
+    # As in the training loop (engine._PreparedBatches): a batch is cut into bf16 patch rows ONCE, when it is prepared (one batch ahead), and the look-ahead
+    # teacher and -- one step later -- the student read the same rows.  Every step still prepares exactly one batch.
+    row_dtypes = engine.row_dtypes_for(student, teacher)
+    prepare = (lambda: ops.patch_rows(img, dtypes=row_dtypes)) if row_dtypes else (lambda: img)
+    cur = prepare()
     if look is not None:
-        look.submit(img)
+        look.submit(cur)
 
     feed = None
     if args.host_input:
@@ -372,21 +377,23 @@ def main():
             def __iter__(self): return (self.batch for _ in range(self.n))
         host = (img.cpu().pin_memory(), soft.cpu().pin_memory())
         if look is not None:
-            look.take(img)
-        feed = iter(engine._PreparedBatches(_Repeat(host, args.warmup + args.steps), dev, None, look))
+            look.take(cur)
+        feed = iter(engine._PreparedBatches(_Repeat(host, args.warmup + args.steps + 2), dev, None, look, row_dtypes=row_dtypes))   # (+ the two idle-queue steps)
 
     opt_events = None        # instrumented step: events around the optimizer tail (clip + AdamW + EMA + bf16 re-cast)
 
     def step():
+        nonlocal cur
         opt.zero_grad()
         t_out = None
         if feed is not None:
             x, y, t_out = next(feed)
+        elif look is not None:
+            x, y, t_out = cur, soft, look.take(cur)
+            cur = prepare()                      # the next batch (the same synthetic images again), prepared one step ahead
+            look.submit(cur)
         else:
-            x, y = img, soft
-            if look is not None:
-                t_out = look.take(img)
-                look.submit(img)
+            x, y = prepare(), soft               # (teacher inside the step: both models read the one set of rows)
         out = engine.distill_forward(student, teacher, x, y, gama=(0.2, 0.1, 0.3), criterion=criterion,
                                      teacher_outputs=t_out)
         out["loss"].backward()
@@ -466,7 +473,7 @@ def main():
         assert next(feed, None) is None       # the prefetcher is drained (its last batch submits no look-ahead)
         feed = None
     elif look is not None:
-        look.take(img)
+        look.take(cur)
     look = None
     step()
     torch.cuda.synchronize()

@@ -126,6 +126,22 @@ def _teacher_forward_async(teacher_model, samples):
     return join
 
 
+def row_dtypes_for(*models):
+    """The 16-bit patch-row types one im2row pass must produce so that every model of the step can read it (ops.patch_rows(dtypes=...)); None when
+    a model runs the exact-fp32 kernels (they read the images themselves) or is not on a GPU."""
+    out = []
+    for m in models:
+        if m is None:
+            continue
+        prec = getattr(m, "precision", "bf16")
+        if prec == "f32" or not any(p.is_cuda for p in m.parameters()):
+            return None
+        dt = torch.float16 if prec == "f16" else torch.bfloat16
+        if dt not in out:
+            out.append(dt)
+    return tuple(out) or None
+
+
 class TeacherLookahead:
     """Frozen-teacher forward one batch ahead (engine.py:73-76 computes it inside the step).
 
@@ -160,8 +176,11 @@ class _PreparedBatches:
     """data_loader -> (samples on device after mixup, targets, teacher outputs or None), one batch ahead when a
     TeacherLookahead is given (engine.py:62-68 does the transfer + mixup at the top of each iteration)."""
 
-    def __init__(self, loader, device, mixup_fn, look):
+    def __init__(self, loader, device, mixup_fn, look, row_dtypes=None):
         self.loader, self.device, self.mixup_fn, self.look = loader, device, mixup_fn, look
+        # 16-bit types of the patch rows the step's models read (row_dtypes_for): a batch that arrives as fp32 images (no device mixup) is cut
+        # into patch rows ONCE here, and the student and the look-ahead teacher share them, as they share the mixed rows when mixup is on
+        self.row_dtypes = row_dtypes
         self._h2d = None
 
     def __len__(self):
@@ -190,6 +209,8 @@ class _PreparedBatches:
         samples, targets = self._to_device(samples, targets)
         if self.mixup_fn is not None:
             samples, targets = self.mixup_fn(samples, targets)
+        if self.row_dtypes and isinstance(samples, torch.Tensor) and samples.is_cuda and samples.dim() == 4:
+            samples = ops.patch_rows(samples, dtypes=self.row_dtypes)
         return samples, targets
 
     def __iter__(self):
@@ -234,7 +255,8 @@ def train_1epoch_qkv(model, teacher_model, criterion, data_loader, optimizer, de
     header = 'Epoch: [{}]'.format(epoch)
     step = 0
     lookahead = bool(getattr(args, "teacher_lookahead", True)) and device is not None and str(device).startswith("cuda")
-    batches = _PreparedBatches(data_loader, device, mixup_fn, TeacherLookahead(teacher_model) if lookahead else None)
+    batches = _PreparedBatches(data_loader, device, mixup_fn, TeacherLookahead(teacher_model) if lookahead else None,
+                               row_dtypes=row_dtypes_for(model, teacher_model))
     for samples, targets, teacher_out in metric_logger.log_every(batches, print_freq, header):
         out = distill_forward(model, teacher_model, samples, targets, gama=args.gama, criterion=criterion,
                               teacher_outputs=teacher_out)
