@@ -33,6 +33,9 @@ def test_header_symbols_exported(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     exported = sorted(set(re.findall(r" T (devit_[a-z0-9_]+)", out)))
     assert set(decl) <= set(exported), sorted(set(decl) - set(exported))
+    # ... and nothing else: the library is built with -fvisibility=hidden (round 5 leaked two C++-mangled internals)
+    other = [l.split()[-1] for l in out.splitlines() if " T " in l and not l.split()[-1].startswith("devit_")]
+    assert other == [], other
     assert set(decl) == set(_lib.SIGNATURES), (sorted(set(decl) ^ set(_lib.SIGNATURES)))
     for name in decl:
         assert hasattr(lib, name)
@@ -137,18 +140,19 @@ def test_integration_doc_stub_matches_binding():
     assert f"all {len(_lib.SIGNATURES)} symbols" in doc, "INTEGRATION.md quotes a stale symbol count"
 
 
-def test_gemm4_inc_is_current(tmp_path):
-    """csrc/gemm4_kloop.inc (the four-wave GEMM's K loop as inline asm) is GENERATED: tools/gen_gemm4.py must reproduce the
-    committed file byte for byte, so that the asm in the tree is the asm the documented generator emits."""
+def test_gemm4_inc_is_current(lib, tmp_path):
+    """csrc/gemm4_kloop.inc (the four-wave GEMM's K loop as inline asm) is GENERATED by build.sh (round 6: no longer committed): tools/gen_gemm4.py
+    must reproduce the file the library was built from byte for byte, so that the asm in the library is the asm the documented generator emits
+    (`lib`: a tree that was never built is built first)."""
     out = tmp_path / "gemm4_kloop.inc"
     env = {k: v for k, v in os.environ.items() if not k.startswith("GEMM4_")}      # (the experiment switches of the generator off)
     subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_gemm4.py"), str(out)], env=env)
     assert out.read_bytes() == open(os.path.join(ROOT, "devit_amd", "csrc", "gemm4_kloop.inc"), "rb").read()
 
 
-def test_gemmfr_inc_is_current(tmp_path):
-    """csrc/gemmfr_kloop.inc (the full-row 256x384 GEMM's K loop as inline asm) is GENERATED: tools/gen_gemmfr.py must reproduce the
-    committed file byte for byte."""
+def test_gemmfr_inc_is_current(lib, tmp_path):
+    """csrc/gemmfr_kloop.inc (the K loops of the full-row 256x384 GEMM and of the grouped weight-gradient kernel as inline asm) is GENERATED by
+    build.sh: tools/gen_gemmfr.py must reproduce the file the library was built from byte for byte."""
     out = tmp_path / "gemmfr_kloop.inc"
     env = {k: v for k, v in os.environ.items() if not k.startswith("GEMMFR_")}     # (the experiment switches of the generator off)
     subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_gemmfr.py"), str(out)], env=env)
