@@ -84,6 +84,32 @@ def test_wgrad_exact_and_linear_full_size(dev):
     assert torch.equal(out, 2 * ref)
 
 
+def test_grouped_wgrads_exact_and_linear_full_size(dev):
+    """The step's weight gradients as the step launches them (round 6): ONE launch of the grouped full-row kernel over the products of eleven
+    blocks at all 50688 rows (44 jobs, 209 tiles, no K split) and one block's four products alone (13 K slices of atomics).  Integer operands:
+    every product and every fused bias gradient is exact whatever the order of the adds; two launches add (accumulate-into-`.grad` contract)."""
+    from devit_amd import ops
+    D, Hd, NB = 384, 1536, 11
+    shapes = ((3 * D, D), (D, D), (Hd, D), (D, Hd))
+    sets = [[(ints((M, n), -2, 2, dev, 40 + 10 * s + i).to(BF16), ints((M, k), -2, 2, dev, 60 + 10 * s + i).to(BF16)) for i, (n, k) in enumerate(shapes)]
+            for s in range(2)]                                        # two blocks' operands, used alternately
+    refs = [[dy.float().t() @ x.float() for dy, x in st] for st in sets]
+    gw = [[torch.zeros(sh, dtype=F32, device=dev) for sh in shapes] for _ in range(NB)]
+    gb = [[torch.zeros(sh[0], dtype=F32, device=dev) for sh in shapes] for _ in range(NB)]
+    jobs = [(sets[l & 1][i][0], sets[l & 1][i][1], gw[l][i], gb[l][i] if i != 3 else None) for l in range(NB) for i in range(4)]
+    for _ in range(2):
+        ops.linear_wgrads(jobs, M)
+    for l in range(NB):
+        for i in range(4):
+            assert torch.equal(gw[l][i], 2 * refs[l & 1][i]), (l, i)
+            if i != 3:
+                assert torch.equal(gb[l][i], 2 * sets[l & 1][i][0].float().sum(0)), (l, i)
+    one = [torch.zeros(sh, dtype=F32, device=dev) for sh in shapes]
+    ops.linear_wgrads([(sets[0][i][0], sets[0][i][1], one[i], None) for i in range(4)], M)      # 19 tiles x 13 slices
+    for i in range(4):
+        assert torch.equal(one[i], refs[0][i]), i
+
+
 def test_attention_rows_sum_to_gate_full_size(dev):
     """V = 1 everywhere -> every output element is gate_h * sum_j P_ij = gate_h (P is rounded to bf16 before P V, so to
     2^-8); and the log-sum-exp of a constant score row is log N + the score."""
