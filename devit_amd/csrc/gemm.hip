@@ -1644,11 +1644,25 @@ extern "C" int devit_wgrad_grouped(const devit_wgrad_job* jobs, int njobs, int K
     cus = n;
   }
   const int nk_total = K / BK;
-  if (split_k <= 0) {                        // one round of resident workgroups (one per CU), as many slices as give each >= 3 K-steps
+  if (split_k <= 0) {
+    // K slices by a two-term cost model (microseconds), both terms measured (profiles/r06_a_wgradfr_*.txt, r06_H_*): a workgroup walks a K-step in
+    // ~2.1 us (the launch is bound by the LDS-DMA stream out of HBM), workgroups run one per CU in rounds of `avail`; every (tile, slice) leaves through
+    // 384 KB of fp32 atomics, which the memory side retires at ~1.3 TB/s chip-wide whoever issues them (0.30 us each).  One block: 19 tiles -> 13 slices
+    // (202 us modelled, 200-230 measured); eleven blocks: 209 tiles -> no split (1723 / 1720); a compacted student's 162 tiles -> 3 slices (two rounds
+    // of a third of the K loop instead of one round on 162 of 256 CUs).
     const int avail = cus - reserved_cus() >= 8 ? cus - reserved_cus() : 8;
-    split_k = avail / tiles;
-    if (split_k < 1) split_k = 1;
-    if (split_k > nk_total / 3) split_k = nk_total / 3;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sk = 1; sk <= 64 && nk_total / sk >= 3; ++sk) {
+      const long long units = (long long)tiles * sk;
+      const double rounds = (double)((units + avail - 1) / avail);
+      const double cost = 2.1 * ((nk_total + sk - 1) / sk) * rounds + 0.30 * (double)units;
+      if (cost < best_cost - 1e-9) {
+        best_cost = cost;
+        best = sk;
+      }
+    }
+    split_k = best;
   }
   DEVIT_CHECK(split_k >= 1 && nk_total / split_k >= 3, DEVIT_ERR_SHAPE, "devit_wgrad_grouped: K=%d gives %d K-steps, fewer than 3 per slice at split_k=%d",
               K, nk_total, split_k);
