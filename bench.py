@@ -369,7 +369,7 @@ def main():
     if look is not None:
         look.submit(cur)
 
-    feed = None
+    feed = feed_batches = None
     if args.host_input:
         class _Repeat:                       # a loader that hands out the same pinned host batch
             def __init__(self, batch, n): self.batch, self.n = batch, n
@@ -378,7 +378,8 @@ def main():
         host = (img.cpu().pin_memory(), soft.cpu().pin_memory())
         if look is not None:
             look.take(cur)
-        feed = iter(engine._PreparedBatches(_Repeat(host, args.warmup + args.steps + 2), dev, None, look, row_dtypes=row_dtypes))   # (+ the two idle-queue steps)
+        feed_batches = engine._PreparedBatches(_Repeat(host, args.warmup + args.steps + 2), dev, None, look, row_dtypes=row_dtypes)   # (+ the two idle-queue steps)
+        feed = iter(feed_batches)
 
     opt_events = None        # instrumented step: events around the optimizer tail (clip + AdamW + EMA + bf16 re-cast)
 
@@ -391,11 +392,12 @@ def main():
         elif look is not None:
             x, y, t_out = cur, soft, look.take(cur)
             cur = prepare()                      # the next batch (the same synthetic images again), prepared one step ahead
-            look.submit(cur)
+            look.submit(cur, defer=True)         # launched behind the student's forward (after_student below), as in the training loop
         else:
             x, y = prepare(), soft               # (teacher inside the step: both models read the one set of rows)
+        launch = (feed_batches.launch_teacher if feed is not None else (look.launch if look is not None else None))
         out = engine.distill_forward(student, teacher, x, y, gama=(0.2, 0.1, 0.3), criterion=criterion,
-                                     teacher_outputs=t_out)
+                                     teacher_outputs=t_out, after_student=launch)
         out["loss"].backward()
         if opt_events is not None:
             opt_events.append(torch.cuda.Event(enable_timing=True))

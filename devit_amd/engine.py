@@ -43,9 +43,10 @@ def _side_forward(teacher_model, samples, main, side):
 
 
 def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3), kind="hard", alpha=0.5, tau=1.0,
-                    criterion=None, dp_scales="draw", teacher_outputs=None):
+                    criterion=None, dp_scales="draw", teacher_outputs=None, after_student=None):
     """One DEKD forward.  Returns dict(loss, cls_loss, q_loss, k_loss, v_loss, logits, teacher_logits).
-    teacher_outputs: the teacher's outputs for `samples` if they were computed ahead (TeacherLookahead)."""
+    teacher_outputs: the teacher's outputs for `samples` if they were computed ahead (TeacherLookahead).
+    after_student: called once the student's forward is enqueued (TeacherLookahead.launch of the NEXT batch)."""
     vit = model.module if hasattr(model, "module") else model
     # only the middle block's q/k/v enter the relation loss (engine.py:91-100): the other blocks' packed qkv buffers
     # need no zeroed overhang rows
@@ -62,6 +63,8 @@ def distill_forward(model, teacher_model, samples, targets, gama=(0.2, 0.1, 0.3)
         else:
             outputs = model(samples, output_qkv=True)                               # engine.py:70
     logits, qkvs = outputs['output'], outputs['qkv']
+    if after_student is not None:
+        after_student()
     if teacher_outputs is None:                                                     # engine.py:73-76
         teacher_outputs = pre_teacher() if pre_teacher is not None else _teacher_forward(teacher_model, samples)
     teacher_logits, teacher_qkvs = teacher_outputs['output'], teacher_outputs['qkv']
@@ -160,14 +163,26 @@ class TeacherLookahead:
             teacher_model.qkv_pad_layers = {len(teacher_model.blocks) // 2 - 1}
         self._pending = None
 
-    def submit(self, samples):
+    def submit(self, samples, defer=False):
+        """defer: record the batch, enqueue its forward at launch() (or at take(), at the latest).  Round 6: the loop launches the NEXT batch's
+        teacher forward behind the student's forward of the current one (distill_forward(after_student=...)) instead of in front of it: the side
+        stream then starts when the student forward has drained, and the teacher runs beside the backward -- whose launches leave CUs idle (198-tile
+        dgrads, attention, LayerNorm) -- and the next forward's first half, not beside a forward of CU-filling GEMMs that it only delays.  Same
+        arithmetic, +0.9 % (three interleaved pairs: 11372 / 11407 / 11395 -> 11487 / 11488 / 11552 img/s).  DEVIT_TEACHER_SUBMIT=early: as before."""
         if self._pending is not None:
             raise RuntimeError("TeacherLookahead.submit: the previous batch was not taken")
-        self._pending = (samples, _teacher_forward_async(self.teacher, samples))
+        self._pending = [samples, None]
+        if not defer or os.environ.get("DEVIT_TEACHER_SUBMIT", "late") == "early":
+            self.launch()
+
+    def launch(self):
+        if self._pending is not None and self._pending[1] is None:
+            self._pending[1] = _teacher_forward_async(self.teacher, self._pending[0])
 
     def take(self, samples):
         if self._pending is None or self._pending[0] is not samples:
             raise RuntimeError("TeacherLookahead.take: not the batch that was submitted")
+        self.launch()
         join, self._pending = self._pending[1], None
         return join()
 
@@ -213,6 +228,11 @@ class _PreparedBatches:
             samples = ops.patch_rows(samples, dtypes=self.row_dtypes)
         return samples, targets
 
+    def launch_teacher(self):
+        """distill_forward(after_student=...): the student's forward of the current batch is enqueued -- now the next batch's teacher forward"""
+        if self.look is not None:
+            self.look.launch()
+
     def __iter__(self):
         it = iter(self.loader)
         cur = next(it, None)
@@ -228,7 +248,7 @@ class _PreparedBatches:
             if self.look is not None:
                 t_out = self.look.take(cur[0])
                 if nxt is not None:
-                    self.look.submit(nxt[0])
+                    self.look.submit(nxt[0], defer=True)      # launched by launch_teacher() behind the student's forward, or by the next take()
             yield cur[0], cur[1], t_out
             cur = nxt
 
@@ -259,7 +279,7 @@ def train_1epoch_qkv(model, teacher_model, criterion, data_loader, optimizer, de
                                row_dtypes=row_dtypes_for(model, teacher_model))
     for samples, targets, teacher_out in metric_logger.log_every(batches, print_freq, header):
         out = distill_forward(model, teacher_model, samples, targets, gama=args.gama, criterion=criterion,
-                              teacher_outputs=teacher_out)
+                              teacher_outputs=teacher_out, after_student=batches.launch_teacher)
         loss = out['loss']
         log_now = (step % print_freq == 0)
         if log_now:

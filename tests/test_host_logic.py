@@ -113,10 +113,13 @@ def test_prepared_batches_lookahead_order():
         def __init__(self):
             self.pending, self.log = None, []
 
-        def submit(self, samples):
+        def submit(self, samples, defer=False):
             assert self.pending is None
             self.pending = samples
-            self.log.append(("submit", float(samples[0])))
+            self.log.append(("submit", float(samples[0])) + (("deferred",) if defer else ()))
+
+        def launch(self):
+            self.log.append(("launch", float(self.pending[0])))
 
         def take(self, samples):
             assert self.pending is samples
@@ -130,7 +133,33 @@ def test_prepared_batches_lookahead_order():
     got = list(engine._PreparedBatches(loader, "cpu", mix, look))
     assert [float(s[0]) for s, _, _ in got] == [0.5, 1.5, 2.5, 3.5]
     assert [float(o["output"][0]) for _, _, o in got] == [5.0, 15.0, 25.0, 35.0]
-    assert look.log[:4] == [("submit", 0.5), ("take", 0.5), ("submit", 1.5), ("take", 1.5)] and look.pending is None
+    # the first batch's teacher forward is enqueued at once; every later one is recorded and launched by launch_teacher() (the loop calls it behind the
+    # student's forward: distill_forward(after_student=...)) or, at the latest, by the take()
+    assert look.log[:4] == [("submit", 0.5), ("take", 0.5), ("submit", 1.5, "deferred"), ("take", 1.5)] and look.pending is None
+    look2 = FakeLook()
+    batches = engine._PreparedBatches(loader, "cpu", mix, look2)
+    for _ in batches:
+        batches.launch_teacher()
+        break
+    assert look2.log == [("submit", 0.5), ("take", 0.5), ("submit", 1.5, "deferred"), ("launch", 1.5)]
+    # the real look-ahead object: a deferred submit launches at launch() or at take(), never twice
+    calls = []
+    real = engine.TeacherLookahead.__new__(engine.TeacherLookahead)
+    real.teacher, real._pending = None, None
+    orig = engine._teacher_forward_async
+    engine._teacher_forward_async = lambda teacher, samples: (calls.append(float(samples[0])), (lambda: {"output": samples}))[1]
+    try:
+        a, b = torch.tensor([1.0]), torch.tensor([2.0])
+        real.submit(a, defer=True)
+        assert calls == []
+        real.launch(); real.launch()
+        assert calls == [1.0] and real.take(a)["output"] is a
+        real.submit(b, defer=True)
+        assert real.take(b)["output"] is b and calls == [1.0, 2.0]
+        with pytest.raises(RuntimeError):
+            real.take(b)
+    finally:
+        engine._teacher_forward_async = orig
     assert len(engine._PreparedBatches(loader, "cpu", None, None)) == 4
     assert [o for _, _, o in engine._PreparedBatches(loader, "cpu", None, None)] == [None] * 4
     assert list(engine._PreparedBatches([], "cpu", None, look)) == []
