@@ -172,20 +172,10 @@ def linear_wgrad(dy, x, w_grad, b_grad, M, **kw):
 
 def wgrad_jobs_ok(mp, jobs):
     """Can these weight gradients run as ONE launch of the full-row weight-gradient kernel (devit_wgrad_grouped)?  jobs: (dy, x, w_grad, b_grad)
-    as linear_wgrad takes them.  One side of every product must be exactly 384 features wide (the student's D), the other a multiple of 128;
-    DEVIT_WGRADFR=0 keeps the four split-K launches on 128x128 tiles."""
-    if os.environ.get("DEVIT_WGRADFR", "1") == "0" or mp % 64 or mp // 64 < 3 or len(jobs) > L.WGRAD_MAX_JOBS:
-        return False
-    tiles = 0
-    for dy, x, w_grad, _ in jobs:
-        N, K = w_grad.shape
-        if K == 384 and N % 128 == 0:
-            tiles += (N + 255) // 256
-        elif N == 384 and K % 128 == 0:
-            tiles += (K + 255) // 256
-        else:
-            return False
-    return tiles <= 256
+    as linear_wgrad takes them.  One side of every product must be exactly 384 features wide (the student's D), the other a multiple of 128
+    (wgrad_job_struct says which); DEVIT_WGRADFR=0 keeps the split-K launches on 128x128 tiles."""
+    return wgrad_enabled(mp) and len(jobs) <= L.WGRAD_MAX_JOBS and all(
+        (w.shape[1] == 384 and w.shape[0] % 128 == 0) or (w.shape[0] == 384 and w.shape[1] % 128 == 0) for _, _, w, _ in jobs)
 
 
 def linear_wgrads(jobs, M, split_k=0):
